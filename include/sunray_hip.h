@@ -1,0 +1,369 @@
+/*
+ * sunray_hip.h — C ABI of the MI355X-native ray-tracing hot path
+ * (ray_gen -> BVH traversal -> ray/triangle intersect -> closest_hit / any_hit / miss shading).
+ *
+ * This header is the drop-in boundary. Every entry point replaces one interface
+ * of the reference (kalsifer-742/sunray, paths relative to its repo root); the reference-side
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no C++/torch types cross this boundary.
+ *   - Every function returns an int status: 0 = SR_OK, negative = SrStatus. The text of the last
+ *     error on the calling thread is available from sr_last_error() (mirrors SrError{source,
+ *     description}, src/error.rs:6-46). Nothing throws or aborts across the ABI.
+ *   - "device pointer" = HIP device memory of the GPU the scene was created on (hipMalloc, a torch
+ *     tensor's data_ptr(), ...). The caller owns every frame buffer; the library owns only the
+ *     scene (mesh tables, BVH) — the ownership split of src/lib.rs:131-153 / 788-793.
+ *   - All launches are asynchronous on the caller's hipStream_t (passed as void*); the caller
+ *     synchronises, as the reference's caller does with wait_frame (src/lib.rs:1227-1229).
+ *   - One context/scene per GPU; single caller thread per scene (the reference's Renderer is
+ *     !Send, src/vulkan_abstraction/core/mod.rs:25).
+ *
+ * Struct layouts T1..T9 are byte-exact mirrors of shaders/rt_types.slang and of the #[repr(C)]
+ * Rust structs that feed them; static asserts at the bottom pin the sizes.
+ */
+#ifndef SUNRAY_HIP_H
+#define SUNRAY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* Status codes — mirror ErrorSource (src/error.rs:11-22)                                       */
+/* ------------------------------------------------------------------------------------------ */
+typedef enum SrStatus {
+    SR_OK = 0,
+    SR_ERR_INVALID_ARG = -1, /* ErrorSource::Custom: builder/loader misuse (pass_builder.rs:258-294, lib.rs:880-901) */
+    SR_ERR_HIP = -2,         /* ErrorSource::Vulkan counterpart: a HIP runtime call failed            */
+    SR_ERR_OOM = -3,         /* ErrorSource::GpuAllocator                                            */
+    SR_ERR_STATE = -4,       /* ErrorSource::RenderGraph: call order violated (e.g. trace before build) */
+    SR_ERR_UNSUPPORTED = -5  /* feature outside the built scope (e.g. textured materials, §8f#3)     */
+} SrStatus;
+
+#define SR_NULL_TEXTURE 0xFFFFFFFFu /* rt_types.slang:192, resources/material.rs:49 */
+
+/* ------------------------------------------------------------------------------------------ */
+/* T1  VertexAttributes (rt_types.slang:24-36) / Vertex (gltf/vertex.rs:1-35) — 96 B            */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct SrVertex {
+    float position[3];
+    float _pad0;
+    float normal[3];
+    float _pad1;
+    float tangent[4];
+    float base_color_tex_coord[2];
+    float metallic_roughness_tex_coord[2];
+    float normal_tex_coord[2];
+    float occlusion_tex_coord[2];
+    float emissive_tex_coord[2];
+    float _pad3[2];
+} SrVertex;
+
+/* Material (resources/material.rs:15-44) — 112 B, the inlined material_* half of MeshInfo. */
+typedef struct SrMaterial {
+    float base_color_value[4];
+    float metallic_factor;
+    float roughness_factor;
+    float _pad_mid[2];
+    float emissive_factor[4]; /* rgb + strength */
+    uint32_t alpha_mode;      /* always 0 in the reference (material.rs:74) */
+    float alpha_cutoff;
+    float transmission_factor;
+    float ior;
+    uint32_t base_color_image, base_color_sampler;
+    uint32_t metallic_roughness_image, metallic_roughness_sampler;
+    uint32_t normal_image, normal_sampler;
+    uint32_t occlusion_image, occlusion_sampler;
+    uint32_t emissive_image, emissive_sampler;
+    uint32_t _pad_end[2];
+} SrMaterial;
+
+/* T2  MeshInfo (rt_types.slang:61-86) / EntityGpuData (resources/entity.rs:8-13) — 128 B */
+typedef struct SrMeshInfo {
+    uint64_t vertices; /* device address of SrVertex[]  */
+    uint64_t indices;  /* device address of uint32_t[]  */
+    SrMaterial material;
+} SrMeshInfo;
+
+/* T3  EmissiveTriangle (rt_types.slang:89-94, gltf/emissive_triangle.rs:6-13) — 64 B */
+typedef struct SrEmissiveTriangle {
+    float v0[4], v1[4], v2[4]; /* local space, w unused */
+    float emission[4];         /* rgb = factor * strength */
+} SrEmissiveTriangle;
+
+/* T4  EmissiveIndirectionEntry (rt_types.slang:96-99) — 8 B */
+typedef struct SrEmissiveIndirectionEntry {
+    uint32_t blas_tri_index; /* slot in the emissive-triangle table */
+    uint32_t entity_id;      /* instance index into the transform table */
+} SrEmissiveIndirectionEntry;
+
+/* T5  EntityTransform (rt_types.slang:101-103) = VkTransformMatrixKHR, row-major 3x4 (utils.rs:67-74) — 48 B */
+typedef struct SrTransform {
+    float m[12];
+} SrTransform;
+
+/* T6  Matrices (rt_types.slang:115-120) — 256 B. Each float[16] holds the four ROWS of the
+ * matrix (the host uploads the transpose of nalgebra's column-major storage, lib.rs:1023-1047). */
+typedef struct SrMatrices {
+    float view_inverse[16];
+    float proj_inverse[16];
+    float view_proj[16];
+    float prev_view_proj[16];
+} SrMatrices;
+
+/* T7  Reservoir / ReservoirGI (rt_types.slang:123-143, resources/reservoir.rs:6-54) — 48 B each */
+typedef struct SrReservoir {
+    float light_pos[3];
+    float w_sum;
+    float light_normal[3];
+    float M;
+    uint32_t light_idx;
+    float W;
+    uint32_t hit_normal_packed;
+    float depth;
+} SrReservoir;
+
+typedef struct SrReservoirGI {
+    float sample_pos[3];
+    float w_sum;
+    float sample_radiance[3];
+    float M;
+    uint32_t sample_normal_packed;
+    float W;
+    uint32_t hit_normal_packed;
+    float depth;
+} SrReservoirGI;
+
+/* T8  RayPayload (rt_types.slang:9-16) — 32 B */
+typedef struct SrRayPayload {
+    float emission[3];
+    float dist;
+    uint32_t albedo_packed;
+    uint32_t normal_packed;
+    uint32_t material_info;
+    uint32_t transmission_ior_packed;
+} SrRayPayload;
+
+/* RayDesc as passed to TraceRay (ray_gen_ris.slang:70-75) — 32 B */
+typedef struct SrRay {
+    float origin[3];
+    float tmin;
+    float dir[3];
+    float tmax;
+} SrRay;
+
+/* Committed-hit attributes of one closest-hit query — 16 B.
+ * t < 0 (exactly -1.0f) = miss (ray_miss.slang:10-13). tri = global triangle index in
+ * instance-major order (instance i's triangles follow instance i-1's); u,v = barycentric weights
+ * of vertex 1 and 2 (BuiltInTriangleIntersectionAttributes, closest_hit.slang:15-17). */
+typedef struct SrHit {
+    float t;
+    float u;
+    float v;
+    uint32_t tri;
+} SrHit;
+
+/* Compile-time constants of the reference exposed as knobs (SURVEY.md §5 "Config / flags").
+ * sr_trace_config_default() fills the reference values. */
+typedef struct SrTraceConfig {
+    uint32_t max_bounces;     /* BOUNCES = 10            ray_gen_final.slang:41  */
+    uint32_t shadow_bounces;  /* SHADOW_BOUNCES = 5      ray_gen_final.slang:42  */
+    uint32_t ris_candidates;  /* RIS_CANDIDATES = 16     ray_gen_ris.slang:187   */
+    uint32_t virtual_bounces; /* 20                      ray_gen_ris.slang:69    */
+    uint32_t enable_restir;   /* 1 = reference behaviour. 0 = ReSTIR block disabled: the final pass
+                                 starts with restir_evaluated = true, so every rough bounce takes the
+                                 plain NEE branch (ray_gen_final.slang:328-382); the RIS pass is not
+                                 needed (BASELINE.json configs 2, 3, 5).                           */
+    uint32_t _reserved[3];
+} SrTraceConfig;
+
+typedef struct SrScene SrScene; /* opaque: mesh tables + instance tables + BVH ("TLAS") on one GPU */
+
+/* T9  RaytracingPC (rt_types.slang:151-190) / RaytracingHeapPushConstant
+ * (pipelines/ray_tracing_pipeline.rs:28-60), with every heap handle replaced by a pointer and the
+ * dispatch extent (pass_builder.rs:311-320 trace_extent) made explicit. The same params struct is
+ * handed to both passes, as the reference pushes identical bytes to both (lib.rs:1626-1652).
+ *
+ * Image storage follows the reference's formats (lib.rs:1492-1516), one element per pixel, row 0 =
+ * top of the image:
+ *   raw_color      float[4]  fp32 RGBA (reference: B10G11R11_UFLOAT; kept fp32 here)
+ *   depth_img      uint16    R16_SFLOAT bits
+ *   normal_img     uint32    R8G8B8A8_SNORM, normal.xyz + roughness in .a
+ *   diffuse_img    uint32    B10G11R11_UFLOAT_PACK32
+ *   motion_vec_img uint32    R16G16_SFLOAT
+ * meshes_info / emissive_triangles / emissive_indirection / entity_transforms / tlas of the
+ * reference struct are owned by `scene` (sr_scene_* below). */
+typedef struct SrRtParams {
+    const SrScene* scene;
+    float* raw_color;                /* device, 4*W*H floats  */
+    uint16_t* depth_img;             /* device, W*H           */
+    uint32_t* normal_img;            /* device, W*H           */
+    uint32_t* diffuse_img;           /* device, W*H           */
+    uint32_t* motion_vec_img;        /* device, W*H           */
+    const SrMatrices* matrices;      /* HOST pointer, copied into the launch like push data */
+    const uint8_t* blue_noise_tex;   /* device, RGBA8 texels, blue_noise_w*blue_noise_h*4 bytes (lib.rs:281-309) */
+    uint32_t blue_noise_w, blue_noise_h;
+    SrReservoir* reservoirs[2];      /* device, W*H each; ping-pong by frame_count & 1 (rt_utils.slang:241-242) */
+    SrReservoirGI* reservoirs_gi[2]; /* device, W*H each */
+    uint32_t frame_count;            /* relative_frame_count (lib.rs:1355,1386) */
+    uint32_t use_srgb;               /* carried, unused by the shaders */
+    uint32_t width, height;          /* trace_extent[0], [1]; also the image size */
+    /* Sub-rectangle of the image this launch covers, for tile-parallel multi-GPU.
+     * Pixels are keyed by their GLOBAL coordinates (RNG, camera), so any tiling gives identical
+     * values. tile_h == 0 means the whole image. Buffers are always full-size W*H. */
+    uint32_t tile_y0, tile_h;
+    SrTraceConfig config;
+} SrRtParams;
+
+/* Ray counters accumulated by the kernels (rays are counted, not estimated). */
+typedef struct SrRayCounters {
+    uint64_t closest_queries; /* TraceRay(RAY_FLAG_NONE) issued            */
+    uint64_t any_queries;     /* TraceRay(ACCEPT_FIRST_HIT|SKIP_CLOSEST) issued */
+    uint64_t boxes_tested;    /* child boxes tested (32 B each), only in the instrumented build */
+    uint64_t tris_tested;     /* triangle records tested (48 B each), only in the instrumented build */
+} SrRayCounters;
+
+/* ------------------------------------------------------------------------------------------ */
+/* Errors                                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+const char* sr_last_error(void); /* SrError::description of the last failure on this thread */
+int sr_version(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Host-side data preparation — pure CPU, no GPU needed                     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* H1/H2: Camera::as_matrices (src/camera.rs:33-63) followed by the transposed upload of
+ * Renderer::render (src/lib.rs:1017-1048). prev_view_proj16 = the previous frame's view_proj rows
+ * as returned in out->view_proj by the previous call, or NULL on the first frame (zero matrix,
+ * lib.rs:410). */
+int sr_camera_matrices(const float position[3], const float target[3], float fov_y_degrees,
+                       uint32_t width, uint32_t height, const float* prev_view_proj16,
+                       SrMatrices* out);
+
+/* H6: Material::new for a runtime mesh (resources/material.rs:52-92 with the NULL-texture
+ * resolver of lib.rs:937-943): factors copied, alpha_mode = 0, alpha_cutoff = 0, all textures NULL. */
+int sr_material_new(const float base_color[4], float metallic, float roughness,
+                    const float emissive_factor[3], float emissive_strength, float transmission,
+                    float ior, SrMaterial* out);
+
+/* H5: emissive-triangle derivation of Renderer::load_mesh (src/lib.rs:901-925).
+ * Writes at most cap entries, returns the total count through *out_count. */
+int sr_emissive_triangles_from_mesh(const SrVertex* vertices, uint32_t n_vertices,
+                                    const uint32_t* indices, uint32_t n_indices,
+                                    const SrMaterial* material, SrEmissiveTriangle* out,
+                                    uint32_t cap, uint32_t* out_count);
+
+void sr_trace_config_default(SrTraceConfig* out);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Scene = ResourceManager + BLAS/TLAS (resource_manager.rs, acceleration_structure/)           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Renderer::new's resource half (lib.rs:212-446, resource_manager.rs:84-155) on HIP device `device`. */
+int sr_scene_create(int device, SrScene** out);
+int sr_scene_destroy(SrScene* scene);
+
+/* Renderer::load_mesh (src/lib.rs:873-954) + ResourceManager::add_blas (resource_manager.rs:417-447):
+ * validates like the reference (non-empty, index count % 3 == 0, indices in range, key unused),
+ * uploads vertices/indices, assigns the next mesh-info slot (the instance custom index,
+ * closest_hit.slang:18-19) and appends the mesh's emissive triangles to the emissive table.
+ * vertices/indices are HOST pointers. *out_slot may be NULL. */
+int sr_scene_add_mesh(SrScene* scene, uint64_t key, const SrVertex* vertices, uint32_t n_vertices,
+                      const uint32_t* indices, uint32_t n_indices, const SrMaterial* material,
+                      uint32_t* out_slot);
+
+/* ResourceManager::frame_instance_data (resource_manager.rs:216-267) + the dummy-entry padding of
+ * Renderer::render (lib.rs:1058-1081) + the TLAS build it queues (resource_manager.rs:346-363):
+ * keys[i] is instanced counts[i] times with the next counts[i] row-major 3x4 transforms taken from
+ * `transforms`. Instance order, transform table and emissive-indirection order follow the
+ * reference loop exactly. Builds the world-space BVH over every instance's triangles (the
+ * replacement for vkCmdBuildAccelerationStructuresKHR, accel.rs:134-138) and uploads it.
+ * Unknown key -> SR_ERR_INVALID_ARG (resource_manager.rs:227-231). */
+int sr_scene_set_instances(SrScene* scene, const uint64_t* keys, const uint32_t* counts,
+                           uint32_t n_keys, const SrTransform* transforms);
+
+/* Introspection of the tables frame_instance_data produced (host copies; pointers valid until the
+ * next sr_scene_set_instances / destroy). num_lights is the emissive_indirection length the
+ * shaders read through GetDimensions (ray_gen_ris.slang:185-186), i.e. >= 1 because of the dummy. */
+int sr_scene_get_tables(const SrScene* scene, const SrTransform** transforms, uint32_t* n_instances,
+                        const SrEmissiveIndirectionEntry** indirection, uint32_t* num_lights,
+                        const SrEmissiveTriangle** emissive_triangles, uint32_t* n_emissive,
+                        const SrMeshInfo** meshes_info, uint32_t* n_meshes);
+
+/* BVH statistics for roofline accounting. */
+typedef struct SrBvhStats {
+    uint64_t n_triangles;
+    uint64_t n_nodes;     /* inner nodes, 64 B each (two 32-B child boxes) */
+    uint64_t node_bytes;
+    uint64_t tri_bytes;   /* 48 B per triangle record */
+    uint32_t max_depth;
+    float sah_cost;
+    double build_ms;
+} SrBvhStats;
+int sr_scene_bvh_stats(const SrScene* scene, SrBvhStats* out);
+
+/* global triangle index (SrHit.tri) -> (instance index, primitive index) */
+int sr_scene_resolve_triangle(const SrScene* scene, uint32_t tri, uint32_t* instance,
+                              uint32_t* primitive);
+
+/* ------------------------------------------------------------------------------------------ */
+/* The hot path                                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+
+/* TraceRay(tlas, RAY_FLAG_NONE, 0xFF, 0,0,0, ray, prd) minus the closest-hit shader
+ * (ray_gen_ris.slang:75,332; ray_gen_final.slang:80): nearest triangle with tmin < t < tmax,
+ * two-sided (resource_manager.rs:249), all geometry opaque (blas.rs:276).
+ * rays/hits are device pointers to n elements. */
+int sr_trace_closest(const SrScene* scene, const SrRay* rays, uint32_t n, SrHit* hits, void* stream);
+
+/* TraceRay(tlas, ACCEPT_FIRST_HIT_AND_END_SEARCH | SKIP_CLOSEST_HIT_SHADER, ...)
+ * (ray_gen_ris.slang:285-300,372-385; ray_gen_final.slang:203-216,274-287,304-319,361-373):
+ * occluded[i] = 1 if any triangle has tmin < t < tmax, else 0 (the miss shader ran). */
+int sr_trace_any(const SrScene* scene, const SrRay* rays, uint32_t n, uint32_t* occluded, void* stream);
+
+/* closest_hit (closest_hit.slang:12-91) / ray_miss (ray_miss.slang:10-13) applied to hit records:
+ * payloads[i] = the 32-byte RayPayload the reference shader would produce. Device pointers. */
+int sr_shade_closest_hit(const SrScene* scene, const SrHit* hits, uint32_t n, SrRayPayload* payloads,
+                         void* stream);
+
+/* The "raytracing_ris" pass (lib.rs:1662-1705): one ray_gen_ris invocation per pixel
+ * (ray_gen_ris.slang:12-440): G-buffer + ReSTIR-DI reservoir + ReSTIR-GI initial reservoir. */
+int sr_trace_ris(const SrRtParams* params, void* stream);
+
+/* The "raytracing_final" pass (lib.rs:1714-1755): one ray_gen_final invocation per pixel
+ * (ray_gen_final.slang:11-436): writes raw_color. Must be enqueued after sr_trace_ris on the same
+ * stream when config.enable_restir != 0 (the reservoir hand-off edge, lib.rs:1688-1690). */
+int sr_trace_final(const SrRtParams* params, void* stream);
+
+/* Ray counters since the last reset (device-side atomics, read back synchronously). */
+int sr_scene_reset_counters(SrScene* scene, void* stream);
+int sr_scene_read_counters(SrScene* scene, void* stream, SrRayCounters* out);
+
+/* Mean elapsed milliseconds of the traversal kernels launched on `stream` since the last call
+ * (HIP events recorded around every launch of the named kind when timing is enabled). */
+int sr_scene_enable_timing(SrScene* scene, int enable);
+int sr_scene_read_timing(SrScene* scene, double* total_ms, uint32_t* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+
+#if defined(__cplusplus)
+static_assert(sizeof(SrVertex) == 96, "T1");
+static_assert(sizeof(SrMaterial) == 112, "Material");
+static_assert(sizeof(SrMeshInfo) == 128, "T2");
+static_assert(sizeof(SrEmissiveTriangle) == 64, "T3");
+static_assert(sizeof(SrEmissiveIndirectionEntry) == 8, "T4");
+static_assert(sizeof(SrTransform) == 48, "T5");
+static_assert(sizeof(SrMatrices) == 256, "T6");
+static_assert(sizeof(SrReservoir) == 48 && sizeof(SrReservoirGI) == 48, "T7");
+static_assert(sizeof(SrRayPayload) == 32, "T8");
+static_assert(sizeof(SrRay) == 32 && sizeof(SrHit) == 16, "ray/hit");
+#endif
+
+#endif /* SUNRAY_HIP_H */

@@ -1,0 +1,100 @@
+"""Python mirror of include/sunray_hip.h: numpy dtypes and ctypes structures of the C ABI.
+
+Pure data definitions (no library is loaded here). Layouts follow the reference's GPU structs
+(shaders/rt_types.slang) byte for byte; see the header for the file:line of each.
+"""
+import ctypes as C
+
+import numpy as np
+
+NULL_TEXTURE = 0xFFFFFFFF
+
+# T1 VertexAttributes (rt_types.slang:24-36) — 96 B
+VERTEX = np.dtype([
+    ("position", "<f4", 3), ("_pad0", "<f4"), ("normal", "<f4", 3), ("_pad1", "<f4"),
+    ("tangent", "<f4", 4), ("base_color_tex_coord", "<f4", 2), ("metallic_roughness_tex_coord", "<f4", 2),
+    ("normal_tex_coord", "<f4", 2), ("occlusion_tex_coord", "<f4", 2), ("emissive_tex_coord", "<f4", 2),
+    ("_pad3", "<f4", 2)])
+# Material (resources/material.rs:15-44) — 112 B
+MATERIAL = np.dtype([
+    ("base_color_value", "<f4", 4), ("metallic_factor", "<f4"), ("roughness_factor", "<f4"),
+    ("_pad_mid", "<f4", 2), ("emissive_factor", "<f4", 4), ("alpha_mode", "<u4"), ("alpha_cutoff", "<f4"),
+    ("transmission_factor", "<f4"), ("ior", "<f4"),
+    ("base_color_image", "<u4"), ("base_color_sampler", "<u4"),
+    ("metallic_roughness_image", "<u4"), ("metallic_roughness_sampler", "<u4"),
+    ("normal_image", "<u4"), ("normal_sampler", "<u4"),
+    ("occlusion_image", "<u4"), ("occlusion_sampler", "<u4"),
+    ("emissive_image", "<u4"), ("emissive_sampler", "<u4"), ("_pad_end", "<u4", 2)])
+MESH_INFO = np.dtype([("vertices", "<u8"), ("indices", "<u8"), ("material", MATERIAL)])  # T2, 128 B
+EMISSIVE_TRIANGLE = np.dtype([("v0", "<f4", 4), ("v1", "<f4", 4), ("v2", "<f4", 4), ("emission", "<f4", 4)])  # T3
+EMISSIVE_INDIRECTION = np.dtype([("blas_tri_index", "<u4"), ("entity_id", "<u4")])  # T4
+TRANSFORM = np.dtype([("m", "<f4", 12)])  # T5 row-major 3x4
+RESERVOIR = np.dtype([("light_pos", "<f4", 3), ("w_sum", "<f4"), ("light_normal", "<f4", 3), ("M", "<f4"),
+                      ("light_idx", "<u4"), ("W", "<f4"), ("hit_normal_packed", "<u4"), ("depth", "<f4")])  # T7
+RESERVOIR_GI = np.dtype([("sample_pos", "<f4", 3), ("w_sum", "<f4"), ("sample_radiance", "<f4", 3), ("M", "<f4"),
+                         ("sample_normal_packed", "<u4"), ("W", "<f4"), ("hit_normal_packed", "<u4"), ("depth", "<f4")])
+RAY_PAYLOAD = np.dtype([("emission", "<f4", 3), ("dist", "<f4"), ("albedo_packed", "<u4"), ("normal_packed", "<u4"),
+                        ("material_info", "<u4"), ("transmission_ior_packed", "<u4")])  # T8
+RAY = np.dtype([("origin", "<f4", 3), ("tmin", "<f4"), ("dir", "<f4", 3), ("tmax", "<f4")])
+HIT = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("tri", "<u4")])
+
+assert VERTEX.itemsize == 96 and MATERIAL.itemsize == 112 and MESH_INFO.itemsize == 128
+assert EMISSIVE_TRIANGLE.itemsize == 64 and EMISSIVE_INDIRECTION.itemsize == 8 and TRANSFORM.itemsize == 48
+assert RESERVOIR.itemsize == 48 and RESERVOIR_GI.itemsize == 48 and RAY_PAYLOAD.itemsize == 32
+assert RAY.itemsize == 32 and HIT.itemsize == 16
+
+
+class SrMatrices(C.Structure):  # T6, 256 B; every float[16] = 4 rows
+    _fields_ = [("view_inverse", C.c_float * 16), ("proj_inverse", C.c_float * 16),
+                ("view_proj", C.c_float * 16), ("prev_view_proj", C.c_float * 16)]
+
+
+class SrTraceConfig(C.Structure):
+    _fields_ = [("max_bounces", C.c_uint32), ("shadow_bounces", C.c_uint32), ("ris_candidates", C.c_uint32),
+                ("virtual_bounces", C.c_uint32), ("enable_restir", C.c_uint32), ("_reserved", C.c_uint32 * 3)]
+
+    @staticmethod
+    def reference():
+        """The reference's compile-time constants (ray_gen_final.slang:40-42, ray_gen_ris.slang:69,187)."""
+        return SrTraceConfig(10, 5, 16, 20, 1, (C.c_uint32 * 3)(0, 0, 0))
+
+
+class SrRtParams(C.Structure):  # T9
+    _fields_ = [("scene", C.c_void_p), ("raw_color", C.c_void_p), ("depth_img", C.c_void_p),
+                ("normal_img", C.c_void_p), ("diffuse_img", C.c_void_p), ("motion_vec_img", C.c_void_p),
+                ("matrices", C.POINTER(SrMatrices)), ("blue_noise_tex", C.c_void_p),
+                ("blue_noise_w", C.c_uint32), ("blue_noise_h", C.c_uint32),
+                ("reservoirs", C.c_void_p * 2), ("reservoirs_gi", C.c_void_p * 2),
+                ("frame_count", C.c_uint32), ("use_srgb", C.c_uint32),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("tile_y0", C.c_uint32), ("tile_h", C.c_uint32),
+                ("config", SrTraceConfig)]
+
+
+class SrRayCounters(C.Structure):
+    _fields_ = [("closest_queries", C.c_uint64), ("any_queries", C.c_uint64),
+                ("boxes_tested", C.c_uint64), ("tris_tested", C.c_uint64)]
+
+
+class SrBvhStats(C.Structure):
+    _fields_ = [("n_triangles", C.c_uint64), ("n_nodes", C.c_uint64), ("node_bytes", C.c_uint64),
+                ("tri_bytes", C.c_uint64), ("max_depth", C.c_uint32), ("sah_cost", C.c_float),
+                ("build_ms", C.c_double)]
+
+
+def material(base_color=(0.8, 0.8, 0.8, 1.0), metallic=0.0, roughness=0.5, emissive_factor=(0.0, 0.0, 0.0),
+             emissive_strength=0.0, transmission=0.0, ior=1.5):
+    """Material::new for a runtime mesh (resources/material.rs:52-92; all textures NULL, lib.rs:937-943)."""
+    m = np.zeros((), dtype=MATERIAL)
+    m["base_color_value"] = base_color
+    m["metallic_factor"] = metallic
+    m["roughness_factor"] = roughness
+    m["emissive_factor"] = tuple(emissive_factor) + (emissive_strength,)
+    m["transmission_factor"] = transmission
+    m["ior"] = ior
+    for k in ("base_color", "metallic_roughness", "normal", "occlusion", "emissive"):
+        m[k + "_image"] = NULL_TEXTURE
+        m[k + "_sampler"] = NULL_TEXTURE
+    return m
+
+
+IDENTITY_TRANSFORM = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float32)
