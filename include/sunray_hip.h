@@ -311,6 +311,16 @@ int sr_scene_bvh_stats(const SrScene* scene, SrBvhStats* out);
 int sr_scene_resolve_triangle(const SrScene* scene, uint32_t tri, uint32_t* instance,
                               uint32_t* primitive);
 
+/* Host-only access to the BVH builder (no GPU needed): builds the same BVH sr_scene_set_instances
+ * would build over n world-space triangles given as 9 floats each (v0, e1, e2), for structural
+ * checks on machines without a device. nodes: 16 floats per inner node, tris: 12 floats per
+ * triangle in leaf order (layout: sunray_amd/csrc/traverse.h). */
+typedef struct SrHostBvh SrHostBvh;
+int sr_host_bvh_build(const float* v0_e1_e2, uint32_t n_triangles, SrHostBvh** out);
+int sr_host_bvh_get(const SrHostBvh* bvh, const float** nodes, uint32_t* n_nodes, const float** tris,
+                    uint32_t* n_triangles, uint32_t* max_depth);
+int sr_host_bvh_destroy(SrHostBvh* bvh);
+
 /* ------------------------------------------------------------------------------------------ */
 /* The hot path                                                                                 */
 /* ------------------------------------------------------------------------------------------ */
@@ -344,10 +354,16 @@ int sr_trace_final(const SrRtParams* params, void* stream);
 int sr_scene_reset_counters(SrScene* scene, void* stream);
 int sr_scene_read_counters(SrScene* scene, void* stream, SrRayCounters* out);
 
-/* Mean elapsed milliseconds of the traversal kernels launched on `stream` since the last call
- * (HIP events recorded around every launch of the named kind when timing is enabled). */
+/* Instrumented kernels (count child boxes / triangle records tested, SURVEY §8d B_ray accounting).
+ * Off by default: the counting costs registers and time. */
+int sr_scene_set_instrumented(SrScene* scene, int on);
+
+/* Per-launch device timing: when enabled every sr_trace_* launch is bracketed by a HIP event pair
+ * recorded on the launch's own stream. sr_scene_read_timing waits for the recorded launches of one
+ * kind, returns their summed elapsed time and count, and clears that kind's list.
+ * kind: 0 = sr_trace_ris, 1 = sr_trace_final, 2 = sr_trace_closest, 3 = sr_trace_any. */
 int sr_scene_enable_timing(SrScene* scene, int enable);
-int sr_scene_read_timing(SrScene* scene, double* total_ms, uint32_t* n_launches);
+int sr_scene_read_timing(SrScene* scene, int kind, double* total_ms, uint32_t* n_launches);
 
 #ifdef __cplusplus
 }
@@ -364,6 +380,7 @@ static_assert(sizeof(SrMatrices) == 256, "T6");
 static_assert(sizeof(SrReservoir) == 48 && sizeof(SrReservoirGI) == 48, "T7");
 static_assert(sizeof(SrRayPayload) == 32, "T8");
 static_assert(sizeof(SrRay) == 32 && sizeof(SrHit) == 16, "ray/hit");
+static_assert(sizeof(SrTraceConfig) == 32 && sizeof(SrRtParams) == 160, "T9");
 #endif
 
 #endif /* SUNRAY_HIP_H */

@@ -322,7 +322,7 @@ Hit Scene::closest_bvh(V3 o, V3 d, float tmin, float tmax, Counters* c) const {
     V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
     float t_lo = tmin - fabsf(tmin) * 1e-5f;
     float best_t = tmax;
-    float cull = tmax;
+    float cull = tmax + fabsf(tmax) * 1e-5f;  // relaxed on both ends; only intersect_tri applies the exact bounds
     uint32_t stack[96]; int sp = 0;
     stack[sp++] = 0;
     float tn;
@@ -361,11 +361,12 @@ bool Scene::any_bvh(V3 o, V3 d, float tmin, float tmax, Counters* c) const {
     if (nodes.empty()) return false;
     V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
     float t_lo = tmin - fabsf(tmin) * 1e-5f;
+    const float t_hi = tmax + fabsf(tmax) * 1e-5f;
     uint32_t stack[96]; int sp = 0;
     stack[sp++] = 0;
     float tn;
     if (c) c->boxes++;
-    if (!box_hit(nodes[0], o, inv, t_lo, tmax, tn)) return false;
+    if (!box_hit(nodes[0], o, inv, t_lo, t_hi, tn)) return false;
     while (sp > 0) {
         const BvhNode& n = nodes[stack[--sp]];
         if (n.count > 0) {
@@ -377,8 +378,8 @@ bool Scene::any_bvh(V3 o, V3 d, float tmin, float tmax, Counters* c) const {
             continue;
         }
         if (c) c->boxes += 2;
-        if (box_hit(nodes[n.left], o, inv, t_lo, tmax, tn)) stack[sp++] = n.left;
-        if (box_hit(nodes[n.right], o, inv, t_lo, tmax, tn)) stack[sp++] = n.right;
+        if (box_hit(nodes[n.left], o, inv, t_lo, t_hi, tn)) stack[sp++] = n.left;
+        if (box_hit(nodes[n.right], o, inv, t_lo, t_hi, tn)) stack[sp++] = n.right;
     }
     return false;
 }

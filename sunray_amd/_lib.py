@@ -1,0 +1,47 @@
+"""Loader of the in-tree HIP library (sunray_amd/libsunray_hip.so). There is NO fallback path: if
+the library is missing or fails to load, every product entry point raises."""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsunray_hip.so")
+_lib = None
+
+# every symbol include/sunray_hip.h declares
+SYMBOLS = [
+    "sr_last_error", "sr_version", "sr_camera_matrices", "sr_material_new", "sr_emissive_triangles_from_mesh",
+    "sr_trace_config_default", "sr_scene_create", "sr_scene_destroy", "sr_scene_add_mesh", "sr_scene_set_instances",
+    "sr_scene_get_tables", "sr_scene_bvh_stats", "sr_scene_resolve_triangle", "sr_host_bvh_build", "sr_host_bvh_get",
+    "sr_host_bvh_destroy", "sr_trace_closest", "sr_trace_any", "sr_shade_closest_hit", "sr_trace_ris", "sr_trace_final",
+    "sr_scene_reset_counters", "sr_scene_read_counters", "sr_scene_set_instrumented", "sr_scene_enable_timing",
+    "sr_scene_read_timing",
+]
+
+
+class SunrayError(RuntimeError):
+    """SrError (src/error.rs:6-46): status code + description."""
+
+    def __init__(self, code, description):
+        super().__init__("sunray_hip error %d: %s" % (code, description))
+        self.code = code
+        self.description = description
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "sunray_amd: %s is missing — build it with `python -m sunray_amd.build` (or "
+                "__graft_entry__.build()). There is no CPU fallback for the product path." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.sr_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SunrayError(rc, lib().sr_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,469 @@
+// C ABI of the MI355X ray-tracing hot path (include/sunray_hip.h). Each entry point cites the
+// reference interface it replaces in the header; this file is the thin host layer between that ABI,
+// the host-side data preparation (host_prep.cpp, bvh_build.cpp) and the HIP kernels (kernels.hip).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "host.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? SR_ERR_OOM : SR_ERR_HIP,                            \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                             \
+    } while (0)
+
+enum PassKind { kRis = 0, kFinal = 1, kClosest = 2, kAny = 3, kNumKinds = 4 };
+
+struct DeviceBuffer {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int upload(const void* src, size_t n) {
+        if (n > bytes || p == nullptr) {
+            if (p) (void)hipFree(p);
+            p = nullptr; bytes = 0;
+            HIP_TRY(hipMalloc(&p, n ? n : 16));
+            bytes = n ? n : 16;
+        }
+        if (n) HIP_TRY(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
+        return SR_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+}  // namespace
+
+struct SrScene {
+    int device = 0;
+    std::vector<srh::HostMesh> meshes;
+    std::map<uint64_t, uint32_t> slots;
+    std::vector<SrEmissiveTriangle> emissive_tris;
+    std::vector<SrMeshInfo> mesh_infos;
+    srh::FrameInstanceData fid;
+    std::vector<srh::BuildTri> world_tris;
+    DeviceBuffer d_nodes, d_tris, d_meshes, d_instances, d_emissive, d_indirection, d_transforms, d_misc;
+    srd::DevScene dev{};
+    SrBvhStats stats{};
+    bool built = false;
+    int instrumented = 0;
+    int timing = 0;
+    int n_cus = 256;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events[kNumKinds];
+    size_t events_used[kNumKinds] = {0, 0, 0, 0};
+};
+
+namespace {
+
+int bind_device(const SrScene* s) {
+    HIP_TRY(hipSetDevice(s->device));
+    return SR_OK;
+}
+
+// Record a start/stop event pair around a launch when timing is on (bench.py's roofline leg).
+struct ScopedTiming {
+    SrScene* s; int kind; hipStream_t stream; hipEvent_t stop = nullptr;
+    ScopedTiming(SrScene* s_, int kind_, hipStream_t st) : s(s_), kind(kind_), stream(st) {
+        if (!s->timing) return;
+        auto& pool = s->events[kind];
+        size_t& used = s->events_used[kind];
+        if (used == pool.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            pool.emplace_back(a, b);
+        }
+        (void)hipEventRecord(pool[used].first, stream);
+        stop = pool[used].second;
+        used++;
+    }
+    ~ScopedTiming() { if (stop) (void)hipEventRecord(stop, stream); }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* sr_last_error(void) { return g_last_error.c_str(); }
+int sr_version(void) { return 1; }
+
+int sr_camera_matrices(const float position[3], const float target[3], float fov_y_degrees, uint32_t width,
+                       uint32_t height, const float* prev_view_proj16, SrMatrices* out) {
+    if (!position || !target || !out || width == 0 || height == 0) return fail(SR_ERR_INVALID_ARG, "sr_camera_matrices: null argument or empty extent");
+    srh::Camera cam;
+    memcpy(cam.position, position, 12);
+    memcpy(cam.target, target, 12);
+    cam.fov_y = fov_y_degrees;
+    if (!cam.as_matrices(width, height, prev_view_proj16, out)) return fail(SR_ERR_INVALID_ARG, "sr_camera_matrices: singular view/projection matrix");
+    return SR_OK;
+}
+
+int sr_material_new(const float base_color[4], float metallic, float roughness, const float emissive_factor[3],
+                    float emissive_strength, float transmission, float ior, SrMaterial* out) {
+    if (!base_color || !emissive_factor || !out) return fail(SR_ERR_INVALID_ARG, "sr_material_new: null argument");
+    srh::material_new(base_color, metallic, roughness, emissive_factor, emissive_strength, transmission, ior, out);
+    return SR_OK;
+}
+
+int sr_emissive_triangles_from_mesh(const SrVertex* vertices, uint32_t n_vertices, const uint32_t* indices,
+                                    uint32_t n_indices, const SrMaterial* material, SrEmissiveTriangle* out,
+                                    uint32_t cap, uint32_t* out_count) {
+    if (!vertices || !indices || !material || !out_count) return fail(SR_ERR_INVALID_ARG, "sr_emissive_triangles_from_mesh: null argument");
+    for (uint32_t i = 0; i < n_indices; i++)
+        if (indices[i] >= n_vertices) return fail(SR_ERR_INVALID_ARG, "sr_emissive_triangles_from_mesh: index out of range");
+    std::vector<SrEmissiveTriangle> v;
+    srh::emissive_triangles_from_mesh(vertices, indices, n_indices, *material, v);
+    *out_count = (uint32_t)v.size();
+    if (out) memcpy(out, v.data(), sizeof(SrEmissiveTriangle) * std::min<size_t>(cap, v.size()));
+    return SR_OK;
+}
+
+void sr_trace_config_default(SrTraceConfig* out) {
+    if (!out) return;
+    memset(out, 0, sizeof(*out));
+    out->max_bounces = 10;
+    out->shadow_bounces = 5;
+    out->ris_candidates = 16;
+    out->virtual_bounces = 20;
+    out->enable_restir = 1;
+}
+
+int sr_scene_create(int device, SrScene** out) {
+    if (!out) return fail(SR_ERR_INVALID_ARG, "sr_scene_create: out is null");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(SR_ERR_INVALID_ARG, "sr_scene_create: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    SrScene* s = new SrScene();
+    s->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
+    // counters (4 x u64) + queue head, in one small allocation of their own
+    const unsigned long long zeros[8] = {0};
+    int rc = s->d_misc.upload(zeros, sizeof(zeros));
+    if (rc != SR_OK) { delete s; return rc; }
+    *out = s;
+    return SR_OK;
+}
+
+int sr_scene_destroy(SrScene* s) {
+    if (!s) return SR_OK;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    for (auto& m : s->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
+    s->d_nodes.release(); s->d_tris.release(); s->d_meshes.release(); s->d_instances.release();
+    s->d_emissive.release(); s->d_indirection.release(); s->d_transforms.release(); s->d_misc.release();
+    for (auto& pool : s->events) for (auto& e : pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    delete s;
+    return SR_OK;
+}
+
+int sr_scene_add_mesh(SrScene* s, uint64_t key, const SrVertex* vertices, uint32_t n_vertices, const uint32_t* indices,
+                      uint32_t n_indices, const SrMaterial* material, uint32_t* out_slot) {
+    if (!s || !vertices || !indices || !material) return fail(SR_ERR_INVALID_ARG, "load_mesh: null argument");
+    if (s->slots.count(key)) return fail(SR_ERR_INVALID_ARG, "load_mesh: an asset is already registered under this key");
+    if (n_vertices == 0 || n_indices == 0 || (n_indices % 3) != 0) {
+        char buf[200];
+        snprintf(buf, sizeof(buf), "load_mesh: invalid mesh (%u vertices, %u indices — need non-empty vertices and a triangle-list index count)", n_vertices, n_indices);
+        return fail(SR_ERR_INVALID_ARG, buf);
+    }
+    for (uint32_t i = 0; i < n_indices; i++)
+        if (indices[i] >= n_vertices) {
+            char buf[120];
+            snprintf(buf, sizeof(buf), "load_mesh: index %u out of range for %u vertices", indices[i], n_vertices);
+            return fail(SR_ERR_INVALID_ARG, buf);
+        }
+    const uint32_t* tex = &material->base_color_image;
+    for (int i = 0; i < 10; i += 2)
+        if (tex[i] != SR_NULL_TEXTURE) return fail(SR_ERR_UNSUPPORTED, "load_mesh: textured materials are outside the built scope (SURVEY.md §8f #3); pass NULL texture slots");
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    srh::HostMesh m;
+    m.key = key;
+    m.vertices.assign(vertices, vertices + n_vertices);
+    m.indices.assign(indices, indices + n_indices);
+    m.n_vertices = n_vertices; m.n_indices = n_indices;
+    m.material = *material;
+    std::vector<SrEmissiveTriangle> et;
+    srh::emissive_triangles_from_mesh(vertices, indices, n_indices, *material, et);
+    for (const auto& t : et) { m.emissive_slots.push_back((uint32_t)s->emissive_tris.size()); s->emissive_tris.push_back(t); }
+    HIP_TRY(hipMalloc(&m.d_vertices, sizeof(SrVertex) * (size_t)n_vertices));
+    HIP_TRY(hipMemcpy(m.d_vertices, vertices, sizeof(SrVertex) * (size_t)n_vertices, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&m.d_indices, sizeof(uint32_t) * (size_t)n_indices));
+    HIP_TRY(hipMemcpy(m.d_indices, indices, sizeof(uint32_t) * (size_t)n_indices, hipMemcpyHostToDevice));
+    const uint32_t slot = (uint32_t)s->meshes.size();
+    SrMeshInfo mi;
+    mi.vertices = (uint64_t)(uintptr_t)m.d_vertices;
+    mi.indices = (uint64_t)(uintptr_t)m.d_indices;
+    mi.material = *material;
+    s->mesh_infos.push_back(mi);
+    s->slots[key] = slot;
+    s->meshes.push_back(std::move(m));
+    s->built = false;
+    if (out_slot) *out_slot = slot;
+    return SR_OK;
+}
+
+int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* counts, uint32_t n_keys, const SrTransform* transforms) {
+    if (!s || (n_keys && (!keys || !counts))) return fail(SR_ERR_INVALID_ARG, "frame_instance_data: null argument");
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    std::string err;
+    if (!srh::frame_instance_data(s->meshes, s->slots, keys, counts, n_keys, transforms, s->fid, err)) return fail(SR_ERR_INVALID_ARG, err);
+    if (s->fid.n_triangles >= (1u << 28)) return fail(SR_ERR_UNSUPPORTED, "scene exceeds 2^28 triangles (leaf reference encoding)");
+    if (s->emissive_tris.empty()) { SrEmissiveTriangle z; memset(&z, 0, sizeof(z)); s->emissive_tris.push_back(z); }
+    srh::flatten_instances(s->meshes, s->fid, s->world_tris);
+    srh::BvhResult bvh;
+    srh::build_bvh(s->world_tris, (uint32_t)srd::kStackDepth, bvh);
+    if (bvh.max_depth > (uint32_t)srd::kStackDepth) return fail(SR_ERR_STATE, "BVH depth exceeds the traversal stack");
+    // device upload (synchronous, like the reference's scene-load BLAS build: blas.rs:178)
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<srd::DevInstance> dinst(s->fid.instances.size());
+    for (size_t i = 0; i < dinst.size(); i++) {
+        memcpy(dinst[i].o2w, s->fid.instances[i].o2w.m, 48);
+        memcpy(dinst[i].w2o, s->fid.instances[i].w2o, 36);
+        dinst[i].mesh_slot = s->fid.instances[i].mesh_slot;
+        dinst[i].tri_offset = s->fid.instances[i].tri_offset;
+        dinst[i]._pad = 0;
+    }
+    if ((rc = s->d_nodes.upload(bvh.nodes.data(), bvh.nodes.size() * 4)) != SR_OK) return rc;
+    if ((rc = s->d_tris.upload(bvh.tris.data(), bvh.tris.size() * 4)) != SR_OK) return rc;
+    if ((rc = s->d_meshes.upload(s->mesh_infos.data(), s->mesh_infos.size() * sizeof(SrMeshInfo))) != SR_OK) return rc;
+    if ((rc = s->d_instances.upload(dinst.data(), dinst.size() * sizeof(srd::DevInstance))) != SR_OK) return rc;
+    if ((rc = s->d_emissive.upload(s->emissive_tris.data(), s->emissive_tris.size() * sizeof(SrEmissiveTriangle))) != SR_OK) return rc;
+    if ((rc = s->d_indirection.upload(s->fid.emissive_entries.data(), s->fid.emissive_entries.size() * sizeof(SrEmissiveIndirectionEntry))) != SR_OK) return rc;
+    if ((rc = s->d_transforms.upload(s->fid.transforms.data(), s->fid.transforms.size() * sizeof(SrTransform))) != SR_OK) return rc;
+    s->dev.nodes = (const float4*)s->d_nodes.p;
+    s->dev.tris = (const float4*)s->d_tris.p;
+    s->dev.meshes = (const SrMeshInfo*)s->d_meshes.p;
+    s->dev.instances = (const srd::DevInstance*)s->d_instances.p;
+    s->dev.emissive = (const SrEmissiveTriangle*)s->d_emissive.p;
+    s->dev.indirection = (const SrEmissiveIndirectionEntry*)s->d_indirection.p;
+    s->dev.transforms = (const SrTransform*)s->d_transforms.p;
+    s->dev.counters = (unsigned long long*)s->d_misc.p;
+    s->dev.num_lights = (uint32_t)s->fid.emissive_entries.size();
+    s->dev.n_tris = s->fid.n_triangles;
+    s->dev.n_instances = (uint32_t)s->fid.instances.size();
+    s->stats.n_triangles = s->fid.n_triangles;
+    s->stats.n_nodes = bvh.n_nodes;
+    s->stats.node_bytes = (uint64_t)bvh.n_nodes * 64;
+    s->stats.tri_bytes = (uint64_t)s->fid.n_triangles * 48;
+    s->stats.max_depth = bvh.max_depth;
+    s->stats.sah_cost = bvh.sah_cost;
+    s->stats.build_ms = bvh.build_ms;
+    s->built = true;
+    return SR_OK;
+}
+
+int sr_scene_get_tables(const SrScene* s, const SrTransform** transforms, uint32_t* n_instances,
+                        const SrEmissiveIndirectionEntry** indirection, uint32_t* num_lights,
+                        const SrEmissiveTriangle** emissive_triangles, uint32_t* n_emissive,
+                        const SrMeshInfo** meshes_info, uint32_t* n_meshes) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_get_tables: scene is null");
+    if (!s->built) return fail(SR_ERR_STATE, "sr_scene_get_tables: call sr_scene_set_instances first");
+    if (transforms) *transforms = s->fid.transforms.data();
+    if (n_instances) *n_instances = (uint32_t)s->fid.transforms.size();
+    if (indirection) *indirection = s->fid.emissive_entries.data();
+    if (num_lights) *num_lights = (uint32_t)s->fid.emissive_entries.size();
+    if (emissive_triangles) *emissive_triangles = s->emissive_tris.data();
+    if (n_emissive) *n_emissive = (uint32_t)s->emissive_tris.size();
+    if (meshes_info) *meshes_info = s->mesh_infos.data();
+    if (n_meshes) *n_meshes = (uint32_t)s->mesh_infos.size();
+    return SR_OK;
+}
+
+int sr_scene_bvh_stats(const SrScene* s, SrBvhStats* out) {
+    if (!s || !out) return fail(SR_ERR_INVALID_ARG, "sr_scene_bvh_stats: null argument");
+    if (!s->built) return fail(SR_ERR_STATE, "sr_scene_bvh_stats: call sr_scene_set_instances first");
+    *out = s->stats;
+    return SR_OK;
+}
+
+int sr_scene_resolve_triangle(const SrScene* s, uint32_t tri, uint32_t* instance, uint32_t* primitive) {
+    if (!s || !s->built) return fail(SR_ERR_STATE, "sr_scene_resolve_triangle: scene not built");
+    if (tri >= s->fid.n_triangles) return fail(SR_ERR_INVALID_ARG, "sr_scene_resolve_triangle: triangle index out of range");
+    size_t lo = 0, hi = s->fid.instances.size();
+    while (hi - lo > 1) { size_t mid = (lo + hi) / 2; if (s->fid.instances[mid].tri_offset <= tri) lo = mid; else hi = mid; }
+    if (instance) *instance = (uint32_t)lo;
+    if (primitive) *primitive = tri - s->fid.instances[lo].tri_offset;
+    return SR_OK;
+}
+
+static int trace_queue(SrScene* s, const SrRay* rays, uint32_t n, SrHit* hits, uint32_t* occluded, int any, void* stream) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_trace: scene is null");
+    if (!s->built) return fail(SR_ERR_STATE, "sr_trace: call sr_scene_set_instances first (TLAS not built)");
+    if (n && (!rays || (any ? (void*)occluded : (void*)hits) == nullptr)) return fail(SR_ERR_INVALID_ARG, "sr_trace: null ray/output pointer");
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* queue_head = (uint32_t*)((char*)s->d_misc.p + 32);
+    const int n_blocks = s->n_cus * 5;  // 5 x 32 KB of LDS stack per CU: the residency of this kernel
+    ScopedTiming tm(s, any ? kAny : kClosest, st);
+    int e = srk_launch_trace(s->dev, rays, n, hits, occluded, queue_head, any, s->instrumented, n_blocks, st);
+    if (e != 0) return fail(SR_ERR_HIP, std::string("trace kernel launch: ") + hipGetErrorString((hipError_t)e));
+    return SR_OK;
+}
+
+int sr_trace_closest(const SrScene* s, const SrRay* rays, uint32_t n, SrHit* hits, void* stream) {
+    return trace_queue(const_cast<SrScene*>(s), rays, n, hits, nullptr, 0, stream);
+}
+int sr_trace_any(const SrScene* s, const SrRay* rays, uint32_t n, uint32_t* occluded, void* stream) {
+    return trace_queue(const_cast<SrScene*>(s), rays, n, nullptr, occluded, 1, stream);
+}
+
+int sr_shade_closest_hit(const SrScene* s, const SrHit* hits, uint32_t n, SrRayPayload* payloads, void* stream) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_shade_closest_hit: scene is null");
+    if (!s->built) return fail(SR_ERR_STATE, "sr_shade_closest_hit: scene not built");
+    if (n && (!hits || !payloads)) return fail(SR_ERR_INVALID_ARG, "sr_shade_closest_hit: null pointer");
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    int e = srk_launch_shade(s->dev, hits, n, payloads, (hipStream_t)stream);
+    if (e != 0) return fail(SR_ERR_HIP, std::string("shade kernel launch: ") + hipGetErrorString((hipError_t)e));
+    return SR_OK;
+}
+
+static int run_pass(const SrRtParams* p, int which, void* stream) {
+    const char* name = which == 0 ? "raytracing_ris" : "raytracing_final";
+    if (!p || !p->scene) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": params or scene is null");
+    SrScene* s = const_cast<SrScene*>(p->scene);
+    if (!s->built) return fail(SR_ERR_STATE, std::string(name) + ": TLAS not built (call sr_scene_set_instances)");
+    if (p->width == 0 || p->height == 0) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": trace_extent not set");
+    if (!p->matrices) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": matrices is null");
+    const bool need_restir = p->config.enable_restir != 0;
+    if (which == 0 || need_restir) {
+        if (!p->depth_img || !p->normal_img || !p->diffuse_img || !p->motion_vec_img)
+            return fail(SR_ERR_INVALID_ARG, std::string(name) + ": G-buffer image pointer is null");
+        if (!p->reservoirs[0] || !p->reservoirs[1] || !p->reservoirs_gi[0] || !p->reservoirs_gi[1])
+            return fail(SR_ERR_INVALID_ARG, std::string(name) + ": reservoir buffer pointer is null");
+    }
+    if (which == 1) {
+        if (!p->raw_color) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": raw_color is null");
+        if (!p->blue_noise_tex || p->blue_noise_w == 0 || p->blue_noise_h == 0)
+            return fail(SR_ERR_INVALID_ARG, std::string(name) + ": blue-noise texture missing");
+    }
+    if ((uint64_t)p->width * p->height >= (1ull << 31)) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": extent too large");
+    uint32_t y0 = 0, y1 = p->height;
+    if (p->tile_h) {
+        if (p->tile_y0 >= p->height) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": tile outside the image");
+        y0 = p->tile_y0;
+        y1 = std::min(p->height, p->tile_y0 + p->tile_h);
+    }
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    srd::PassArgs a;
+    memset(&a, 0, sizeof(a));
+    a.sc = s->dev;
+    a.mats = *p->matrices;
+    a.raw_color = p->raw_color; a.depth_img = p->depth_img; a.normal_img = p->normal_img;
+    a.diffuse_img = p->diffuse_img; a.motion_vec_img = p->motion_vec_img;
+    a.blue_noise_tex = p->blue_noise_tex; a.blue_noise_w = p->blue_noise_w; a.blue_noise_h = p->blue_noise_h;
+    a.reservoirs[0] = p->reservoirs[0]; a.reservoirs[1] = p->reservoirs[1];
+    a.reservoirs_gi[0] = p->reservoirs_gi[0]; a.reservoirs_gi[1] = p->reservoirs_gi[1];
+    a.frame_count = p->frame_count;
+    a.width = p->width; a.height = p->height;
+    a.y0 = y0; a.y1 = y1;
+    a.tiles_x = (p->width + 15) / 16;
+    a.tiles_y = (y1 - y0 + 15) / 16;
+    a.tiles_per_xcd = (a.tiles_x * a.tiles_y + 7) / 8;
+    a.cfg = p->config;
+    hipStream_t st = (hipStream_t)stream;
+    ScopedTiming tm(s, which == 0 ? kRis : kFinal, st);
+    int e = srk_launch_pass(a, which, s->instrumented, st);
+    if (e != 0) return fail(SR_ERR_HIP, std::string(name) + " launch: " + hipGetErrorString((hipError_t)e));
+    return SR_OK;
+}
+
+int sr_trace_ris(const SrRtParams* params, void* stream) { return run_pass(params, 0, stream); }
+int sr_trace_final(const SrRtParams* params, void* stream) { return run_pass(params, 1, stream); }
+
+int sr_scene_reset_counters(SrScene* s, void* stream) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_reset_counters: scene is null");
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    HIP_TRY(hipMemsetAsync(s->d_misc.p, 0, 32, (hipStream_t)stream));
+    return SR_OK;
+}
+
+int sr_scene_read_counters(SrScene* s, void* stream, SrRayCounters* out) {
+    if (!s || !out) return fail(SR_ERR_INVALID_ARG, "sr_scene_read_counters: null argument");
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    unsigned long long v[4];
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(v, s->d_misc.p, sizeof(v), hipMemcpyDeviceToHost));
+    out->closest_queries = v[0]; out->any_queries = v[1]; out->boxes_tested = v[2]; out->tris_tested = v[3];
+    return SR_OK;
+}
+
+int sr_scene_set_instrumented(SrScene* s, int on) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_set_instrumented: scene is null");
+    s->instrumented = on ? 1 : 0;
+    return SR_OK;
+}
+
+int sr_scene_enable_timing(SrScene* s, int enable) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_enable_timing: scene is null");
+    s->timing = enable ? 1 : 0;
+    for (int k = 0; k < kNumKinds; k++) s->events_used[k] = 0;
+    return SR_OK;
+}
+
+int sr_scene_read_timing(SrScene* s, int kind, double* total_ms, uint32_t* n_launches) {
+    if (!s || kind < 0 || kind >= kNumKinds) return fail(SR_ERR_INVALID_ARG, "sr_scene_read_timing: bad argument");
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    double total = 0.0;
+    for (size_t i = 0; i < s->events_used[kind]; i++) {
+        HIP_TRY(hipEventSynchronize(s->events[kind][i].second));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->events[kind][i].first, s->events[kind][i].second));
+        total += ms;
+    }
+    if (total_ms) *total_ms = total;
+    if (n_launches) *n_launches = (uint32_t)s->events_used[kind];
+    s->events_used[kind] = 0;
+    return SR_OK;
+}
+
+struct SrHostBvhImpl { srh::BvhResult r; uint32_t n; };
+
+int sr_host_bvh_build(const float* v, uint32_t n, SrHostBvh** out) {
+    if (!out || (n && !v)) return fail(SR_ERR_INVALID_ARG, "sr_host_bvh_build: null argument");
+    if (n >= (1u << 28)) return fail(SR_ERR_UNSUPPORTED, "sr_host_bvh_build: too many triangles");
+    std::vector<srh::BuildTri> t(n);
+    for (uint32_t i = 0; i < n; i++) {
+        memcpy(t[i].v0, v + (size_t)i * 9, 12); memcpy(t[i].e1, v + (size_t)i * 9 + 3, 12); memcpy(t[i].e2, v + (size_t)i * 9 + 6, 12);
+        t[i].prim = i; t[i].inst = 0; t[i].gid = i;
+    }
+    auto* h = new SrHostBvhImpl();
+    h->n = n;
+    srh::build_bvh(t, (uint32_t)srd::kStackDepth, h->r);
+    *out = reinterpret_cast<SrHostBvh*>(h);
+    return SR_OK;
+}
+int sr_host_bvh_get(const SrHostBvh* bvh, const float** nodes, uint32_t* n_nodes, const float** tris, uint32_t* n_triangles, uint32_t* max_depth) {
+    if (!bvh) return fail(SR_ERR_INVALID_ARG, "sr_host_bvh_get: null handle");
+    const auto* h = reinterpret_cast<const SrHostBvhImpl*>(bvh);
+    if (nodes) *nodes = h->r.nodes.data();
+    if (n_nodes) *n_nodes = h->r.n_nodes;
+    if (tris) *tris = h->r.tris.data();
+    if (n_triangles) *n_triangles = h->n;
+    if (max_depth) *max_depth = h->r.max_depth;
+    return SR_OK;
+}
+int sr_host_bvh_destroy(SrHostBvh* bvh) { delete reinterpret_cast<SrHostBvhImpl*>(bvh); return SR_OK; }
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+// World-space BVH builder — the replacement for vkCmdBuildAccelerationStructuresKHR
+// (src/vulkan_abstraction/acceleration_structure/accel.rs:134-138) with BLAS inputs as in
+// blas.rs:266-278 (positions = first 12 bytes of each 96-byte vertex, u32 indices, opaque) and TLAS
+// instances as in resource_manager.rs:243-251 (cull-disabled, mask 0xFF).
+//
+// All instances are flattened to world space (288 GB of HBM makes instancing-by-copy affordable
+// and removes the per-instance ray transform from traversal), then a binned-SAH BVH2 is built:
+// 16 bins on each of the three axes, leaves of <= 4 triangles, depth bounded so the per-lane LDS
+// traversal stack (traverse.h kStackDepth) can never overflow. The top of the tree is built by
+// parallel tasks; nodes are emitted in depth-first order so a node's first child follows it.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <future>
+
+#include "host.h"
+
+namespace srh {
+
+namespace {
+
+struct Aabb {
+    float lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; } }
+    void add(const float* p) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    void add(const Aabb& b) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    float half_area() const {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (!(dx >= 0.0f)) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+constexpr int kBins = 16;
+constexpr uint32_t kLeafMax = 4;
+constexpr uint32_t kParallelMin = 1u << 15;
+
+struct Builder {
+    const std::vector<BuildTri>& tris;
+    std::vector<Aabb> bounds;
+    std::vector<float> centroid[3];
+    std::vector<uint32_t> order;
+    uint32_t max_depth;
+    double root_area = 1.0;
+
+    struct Sub {                 // a built subtree with subtree-local node indices
+        std::vector<float> nodes;
+        uint32_t depth = 0;      // inner levels below (and including) its root
+        double cost = 0.0;
+    };
+
+    explicit Builder(const std::vector<BuildTri>& t, uint32_t md) : tris(t), max_depth(md) {}
+
+    static int leaf_ref(uint32_t first, uint32_t count) { return (int)~((first << 3) | count); }
+
+    // Writes child `which`'s box into the 16-float node record (layout: traverse.h).
+    static void put_box(float* n, int which, const Aabb& b) {
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; a++) {   // one ulp of padding each way: boxes stay conservative for
+            lo[a] = std::nextafter(b.lo[a], -INFINITY);  // v0 + e1 rounding and never have zero width
+            hi[a] = std::nextafter(b.hi[a], INFINITY);
+        }
+        if (which == 0) { n[0] = lo[0]; n[1] = hi[0]; n[2] = lo[1]; n[3] = hi[1]; n[8] = lo[2]; n[9] = hi[2]; }
+        else { n[4] = lo[0]; n[5] = hi[0]; n[6] = lo[1]; n[7] = hi[1]; n[10] = lo[2]; n[11] = hi[2]; }
+    }
+    static void put_child(float* n, int which, int ref) { memcpy(n + 12 + which, &ref, 4); }
+
+    Aabb range_bounds(uint32_t first, uint32_t count) const {
+        Aabb b; b.reset();
+        for (uint32_t i = first; i < first + count; i++) b.add(bounds[order[i]]);
+        return b;
+    }
+
+    // Choose the split of [first, first+count); returns the index of the first element of the right half.
+    uint32_t partition(uint32_t first, uint32_t count, uint32_t depth) {
+        const uint32_t last = first + count;
+        // depth guard: a balanced median split needs ceil(log2(count / kLeafMax)) more levels
+        uint32_t need = 0;
+        for (uint32_t c = (count + kLeafMax - 1) / kLeafMax; c > 1; c = (c + 1) / 2) need++;
+        const bool force_median = depth + need + 1 >= max_depth;
+        Aabb cb; cb.reset();
+        for (uint32_t i = first; i < last; i++) {
+            const uint32_t id = order[i];
+            const float c[3] = {centroid[0][id], centroid[1][id], centroid[2][id]};
+            cb.add(c);
+        }
+        int best_axis = -1, best_bin = -1;
+        float best_cost = INFINITY;
+        if (!force_median) {
+            for (int ax = 0; ax < 3; ax++) {
+                const float lo = cb.lo[ax], ext = cb.hi[ax] - cb.lo[ax];
+                if (!(ext > 0.0f)) continue;
+                const float scale = (float)kBins * (1.0f - 1e-6f) / ext;
+                Aabb bb[kBins]; uint32_t bc[kBins];
+                for (int b = 0; b < kBins; b++) { bb[b].reset(); bc[b] = 0; }
+                for (uint32_t i = first; i < last; i++) {
+                    const uint32_t id = order[i];
+                    int b = (int)((centroid[ax][id] - lo) * scale);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    bb[b].add(bounds[id]); bc[b]++;
+                }
+                float ra[kBins]; uint32_t rc[kBins];
+                Aabb acc; acc.reset(); uint32_t n = 0;
+                for (int b = kBins - 1; b >= 1; b--) { acc.add(bb[b]); n += bc[b]; ra[b] = acc.half_area(); rc[b] = n; }
+                acc.reset(); n = 0;
+                for (int b = 0; b < kBins - 1; b++) {
+                    acc.add(bb[b]); n += bc[b];
+                    if (n == 0 || rc[b + 1] == 0) continue;
+                    const float cost = acc.half_area() * (float)n + ra[b + 1] * (float)rc[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = b; }
+                }
+            }
+        }
+        if (best_axis >= 0) {
+            const float lo = cb.lo[best_axis], ext = cb.hi[best_axis] - cb.lo[best_axis];
+            const float scale = (float)kBins * (1.0f - 1e-6f) / ext;
+            const std::vector<float>& cen = centroid[best_axis];
+            auto mid_it = std::partition(order.begin() + first, order.begin() + last, [&](uint32_t id) {
+                int b = (int)((cen[id] - lo) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                return b <= best_bin;
+            });
+            const uint32_t mid = (uint32_t)(mid_it - order.begin());
+            if (mid != first && mid != last) return mid;
+        }
+        // median split along the widest centroid axis (also the depth-guard path)
+        int ax = 0;
+        float e = cb.hi[0] - cb.lo[0];
+        for (int a = 1; a < 3; a++) if (cb.hi[a] - cb.lo[a] > e) { e = cb.hi[a] - cb.lo[a]; ax = a; }
+        const uint32_t mid = first + count / 2;
+        const std::vector<float>& cen = centroid[ax];
+        std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + last,
+                         [&](uint32_t a, uint32_t b) { return cen[a] < cen[b] || (cen[a] == cen[b] && a < b); });
+        return mid;
+    }
+
+    // Builds the subtree over [first, first+count) (count > kLeafMax) into the EMPTY `out`, root at
+    // local index 0. Large halves near the top are built by parallel tasks and merged.
+    void build_sub(uint32_t first, uint32_t count, uint32_t depth, Sub& out) {
+        const uint32_t mid = partition(first, count, depth);
+        const uint32_t cnt[2] = {mid - first, first + count - mid};
+        const uint32_t beg[2] = {first, mid};
+        const bool par = cnt[0] >= kParallelMin && cnt[1] >= kParallelMin && depth < 4;
+        if (!par) {
+            // partition() already ran for this range: redo it inside the in-place builder would change
+            // nothing (the order array is already split), so emit this node here and recurse in place.
+            emit_node(beg, cnt, depth, out, out);
+            return;
+        }
+        Sub child[2];
+        std::future<void> fut = std::async(std::launch::async, [&] { build_sub(beg[1], cnt[1], depth + 1, child[1]); });
+        build_sub(beg[0], cnt[0], depth + 1, child[0]);
+        fut.get();
+        out.nodes.assign(16, 0.0f);
+        uint32_t below = 0;
+        for (int c = 0; c < 2; c++) {
+            const Aabb cb = range_bounds(beg[c], cnt[c]);
+            put_box(&out.nodes[0], c, cb);
+            out.cost += cb.half_area() / root_area;
+            const size_t at = out.nodes.size();
+            const int off = (int)(at / 16);
+            out.nodes.insert(out.nodes.end(), child[c].nodes.begin(), child[c].nodes.end());
+            for (size_t n = at; n < out.nodes.size(); n += 16)
+                for (int k = 0; k < 2; k++) {
+                    int ref; memcpy(&ref, &out.nodes[n + 12 + k], 4);
+                    if (ref >= 0) { ref += off; memcpy(&out.nodes[n + 12 + k], &ref, 4); }
+                }
+            std::vector<float>().swap(child[c].nodes);
+            out.cost += child[c].cost;
+            below = std::max(below, child[c].depth);
+            put_child(&out.nodes[0], c, off);
+        }
+        out.depth = below + 1;
+    }
+    // Emits the node for an already partitioned range into `arr` and builds both halves in place.
+    void emit_node(const uint32_t beg[2], const uint32_t cnt[2], uint32_t depth, Sub& arr, Sub& stats) {
+        const size_t self = arr.nodes.size();
+        arr.nodes.resize(self + 16, 0.0f);
+        uint32_t below = 0;
+        for (int c = 0; c < 2; c++) {
+            const Aabb cb = range_bounds(beg[c], cnt[c]);
+            put_box(&arr.nodes[self], c, cb);
+            stats.cost += cb.half_area() / root_area * (cnt[c] <= kLeafMax ? (double)cnt[c] : 1.0);
+            if (cnt[c] <= kLeafMax) { put_child(&arr.nodes[self], c, leaf_ref(beg[c], cnt[c])); continue; }
+            const int ref = (int)(arr.nodes.size() / 16);
+            Sub sub_stats;
+            build_sub_inplace(beg[c], cnt[c], depth + 1, arr, sub_stats);
+            stats.cost += sub_stats.cost;
+            below = std::max(below, sub_stats.depth);
+            put_child(&arr.nodes[self], c, ref);
+        }
+        stats.depth = below + 1;
+    }
+    // Sequential variant that appends straight into `arr` (node indices are already final within it).
+    void build_sub_inplace(uint32_t first, uint32_t count, uint32_t depth, Sub& arr, Sub& stats) {
+        const uint32_t mid = partition(first, count, depth);
+        const uint32_t cnt[2] = {mid - first, first + count - mid};
+        const uint32_t beg[2] = {first, mid};
+        emit_node(beg, cnt, depth, arr, stats);
+    }
+};
+
+}  // namespace
+
+void flatten_instances(const std::vector<HostMesh>& meshes, const FrameInstanceData& fid, std::vector<BuildTri>& out) {
+    out.clear();
+    out.reserve(fid.n_triangles);
+    for (uint32_t ii = 0; ii < fid.instances.size(); ii++) {
+        const HostInstance& inst = fid.instances[ii];
+        const HostMesh& mesh = meshes[inst.mesh_slot];
+        const float* m = inst.o2w.m;
+        const uint32_t nprim = mesh.n_indices / 3;
+        for (uint32_t p = 0; p < nprim; p++) {
+            float w[3][3];
+            for (int j = 0; j < 3; j++) {
+                const float* q = mesh.vertices[mesh.indices[3 * p + j]].position;
+                // transform_point (rt_utils.slang:278-281): rows dotted with (p, 1), left to right
+                w[j][0] = ((m[0] * q[0] + m[1] * q[1]) + m[2] * q[2]) + m[3] * 1.0f;
+                w[j][1] = ((m[4] * q[0] + m[5] * q[1]) + m[6] * q[2]) + m[7] * 1.0f;
+                w[j][2] = ((m[8] * q[0] + m[9] * q[1]) + m[10] * q[2]) + m[11] * 1.0f;
+            }
+            BuildTri t;
+            for (int a = 0; a < 3; a++) { t.v0[a] = w[0][a]; t.e1[a] = w[1][a] - w[0][a]; t.e2[a] = w[2][a] - w[0][a]; }
+            t.prim = p; t.inst = ii; t.gid = inst.tri_offset + p;
+            out.push_back(t);
+        }
+    }
+}
+
+void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult& res) {
+    const auto t_start = std::chrono::steady_clock::now();
+    const uint32_t n = (uint32_t)tris.size();
+    Builder b(tris, max_depth);
+    b.bounds.resize(n);
+    for (int a = 0; a < 3; a++) b.centroid[a].resize(n);
+    b.order.resize(n);
+    Aabb root; root.reset();
+    for (uint32_t i = 0; i < n; i++) {
+        const BuildTri& t = tris[i];
+        float p1[3], p2[3];
+        for (int a = 0; a < 3; a++) { p1[a] = t.v0[a] + t.e1[a]; p2[a] = t.v0[a] + t.e2[a]; }
+        Aabb bb; bb.reset(); bb.add(t.v0); bb.add(p1); bb.add(p2);
+        b.bounds[i] = bb;
+        for (int a = 0; a < 3; a++) b.centroid[a][i] = 0.5f * bb.lo[a] + 0.5f * bb.hi[a];
+        b.order[i] = i;
+        root.add(bb);
+    }
+    b.root_area = std::max((double)root.half_area(), 1e-30);
+    Builder::Sub top;
+    if (n <= kLeafMax) {
+        // The root must be an inner node: one leaf child + one empty child whose box nothing can hit.
+        top.nodes.assign(16, 0.0f);
+        Aabb none; for (int a = 0; a < 3; a++) { none.lo[a] = INFINITY; none.hi[a] = -INFINITY; }
+        if (n > 0) Builder::put_box(top.nodes.data(), 0, root);
+        else { float* q = top.nodes.data(); q[0] = q[2] = q[8] = INFINITY; q[1] = q[3] = q[9] = -INFINITY; }
+        { float* q = top.nodes.data(); q[4] = q[6] = q[10] = INFINITY; q[5] = q[7] = q[11] = -INFINITY; }
+        (void)none;
+        Builder::put_child(top.nodes.data(), 0, Builder::leaf_ref(0, n));
+        Builder::put_child(top.nodes.data(), 1, Builder::leaf_ref(0, 0));
+        top.depth = 1;
+        top.cost = (double)n;
+    } else {
+        b.build_sub(0, n, 0, top);
+    }
+    res.nodes.swap(top.nodes);
+    res.n_nodes = (uint32_t)(res.nodes.size() / 16);
+    res.max_depth = top.depth;
+    res.sah_cost = (float)top.cost;
+    res.tris.resize((size_t)n * 12);
+    for (uint32_t i = 0; i < n; i++) {
+        const BuildTri& t = tris[b.order[i]];
+        float* q = &res.tris[(size_t)i * 12];
+        q[0] = t.v0[0]; q[1] = t.v0[1]; q[2] = t.v0[2]; q[3] = t.e1[0];
+        q[4] = t.e1[1]; q[5] = t.e1[2]; q[6] = t.e2[0]; q[7] = t.e2[1];
+        q[8] = t.e2[2];
+        memcpy(q + 9, &t.prim, 4); memcpy(q + 10, &t.inst, 4); memcpy(q + 11, &t.gid, 4);
+    }
+    res.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+}
+
+}  // namespace srh

@@ -1,0 +1,74 @@
+// Host-side (C++) counterparts of the reference's Rust host code for the hot path.
+// Names follow the reference: Camera (camera.rs), ResourceManager tables (resource_manager.rs),
+// FrameInstanceData (resource_manager.rs:216-267).
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sunray_hip.h"
+
+namespace srh {
+
+// Camera{position, target, fov_y} (camera.rs:4-8)
+struct Camera {
+    float position[3] = {0.0f, 0.0f, 1.0f};
+    float target[3] = {0.0f, 0.0f, 0.0f};
+    float fov_y = 45.0f;
+    bool as_matrices(uint32_t width, uint32_t height, const float* prev_view_proj16, SrMatrices* out) const;
+};
+
+struct HostMesh {
+    uint64_t key = 0;
+    std::vector<SrVertex> vertices;     // host copy (BVH build reads positions: blas.rs:266-278)
+    std::vector<uint32_t> indices;
+    uint32_t n_vertices = 0, n_indices = 0;
+    SrMaterial material;
+    std::vector<uint32_t> emissive_slots;  // resource_manager.rs:437-446
+    void* d_vertices = nullptr;
+    void* d_indices = nullptr;
+};
+
+struct HostInstance {
+    uint32_t mesh_slot;   // instance custom index (resource_manager.rs:239-246)
+    SrTransform o2w;
+    float w2o[9];
+    uint32_t tri_offset;
+};
+
+struct FrameInstanceData {
+    std::vector<HostInstance> instances;                       // as_instances
+    std::vector<SrTransform> transforms;                       // transforms
+    std::vector<SrEmissiveIndirectionEntry> emissive_entries;  // emissive_entries
+    uint32_t n_triangles = 0;
+};
+
+void material_new(const float base_color[4], float metallic, float roughness, const float emissive_factor[3],
+                  float emissive_strength, float transmission, float ior, SrMaterial* out);
+void emissive_triangles_from_mesh(const SrVertex* vertices, const uint32_t* indices, uint32_t n_indices,
+                                  const SrMaterial& material, std::vector<SrEmissiveTriangle>& out);
+void world_to_object_3x3(const SrTransform& t, float out[9]);
+bool frame_instance_data(const std::vector<HostMesh>& meshes, const std::map<uint64_t, uint32_t>& slots,
+                         const uint64_t* keys, const uint32_t* counts, uint32_t n_keys, const SrTransform* xforms,
+                         FrameInstanceData& out, std::string& err);
+
+// ---- BVH (bvh_build.cpp) ------------------------------------------------------------------------
+// One world-space triangle in the canonical form the kernels intersect.
+struct BuildTri {
+    float v0[3], e1[3], e2[3];
+    uint32_t prim, inst, gid;
+};
+struct BvhResult {
+    std::vector<float> nodes;  // 16 floats (64 B) per inner node
+    std::vector<float> tris;   // 12 floats (48 B) per triangle, leaf order
+    uint32_t n_nodes = 0, max_depth = 0;
+    float sah_cost = 0.0f;
+    double build_ms = 0.0;
+};
+// Flatten every instance's triangles to world space (instance-major order = global triangle index).
+void flatten_instances(const std::vector<HostMesh>& meshes, const FrameInstanceData& fid, std::vector<BuildTri>& out);
+// Binned-SAH BVH2 with depth bounded by `max_depth`, leaves of <= 4 triangles.
+void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult& out);
+
+}  // namespace srh

@@ -1,0 +1,36 @@
+// Kernel argument blocks and host-side launchers shared by kernels.hip and api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "traverse.h"
+
+namespace srd {
+
+// Everything one per-pixel pass needs, passed by value in the kernarg segment — the counterpart of
+// the 144-byte push constant both reference passes receive (rt_types.slang:151-190).
+struct PassArgs {
+    DevScene sc;
+    SrMatrices mats;
+    float* raw_color;
+    uint16_t* depth_img;
+    uint32_t* normal_img;
+    uint32_t* diffuse_img;
+    uint32_t* motion_vec_img;
+    const uint8_t* blue_noise_tex;
+    uint32_t blue_noise_w, blue_noise_h;
+    SrReservoir* reservoirs[2];
+    SrReservoirGI* reservoirs_gi[2];
+    uint32_t frame_count;
+    uint32_t width, height;
+    uint32_t y0, y1;              // rows [y0, y1) of the image are traced by this launch
+    uint32_t tiles_x, tiles_y;    // 16x16 tiles covering width x (y1 - y0)
+    uint32_t tiles_per_xcd;       // ceil(tiles_x * tiles_y / 8)
+    SrTraceConfig cfg;
+};
+
+}  // namespace srd
+
+int srk_launch_trace(const srd::DevScene& sc, const SrRay* rays, uint32_t n, SrHit* hits, uint32_t* occluded,
+                     uint32_t* queue_head, int any, int stats, int n_blocks, hipStream_t stream);
+int srk_launch_shade(const srd::DevScene& sc, const SrHit* hits, uint32_t n, SrRayPayload* out, hipStream_t stream);
+int srk_launch_pass(const srd::PassArgs& args, int which, int stats, hipStream_t stream);

@@ -1,0 +1,745 @@
+// HIP kernels of the ray-tracing hot path for gfx950 (MI355X).
+//
+//   trace_closest_kernel / trace_any_kernel  — persistent-threads ray-queue tracers (K2 / K3)
+//   shade_closest_hit_kernel                 — closest_hit.slang / ray_miss.slang on hit records (K4/K6)
+//   ris_kernel                               — ray_gen_ris.slang:12-440   (K1, K7, K8, K9)
+//   final_kernel                             — ray_gen_final.slang:11-436 (K1, K10)
+//
+// Launch geometry: 256-thread workgroups (4 waves of 64). In the per-pixel passes a workgroup owns a
+// 16x16 pixel tile and each wave an 8x8 sub-tile (coherent primary rays per wave); workgroups are
+// dealt to screen tiles XCD-aware: blocks b and b+8 share an XCD (round-robin dispatch), so XCD x
+// gets the contiguous tile range [x*per_xcd, (x+1)*per_xcd) and its private 4 MiB L2 holds the part
+// of the BVH under that band of the screen.
+#include "kernels.h"
+
+namespace srd {
+
+constexpr int kBlock = 256;
+
+// Wave-wide sum, then one atomic per wave (rays are counted, not estimated: SURVEY.md §8d).
+SRD void flush_counter(unsigned long long* dst, uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, (unsigned long long)v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ray-queue tracers. Persistent threads: the grid is sized to the machine (blocks_per_cu * 256 CUs),
+// each wave pulls 64 rays at a time from a global queue head until the queue is empty.
+// ---------------------------------------------------------------------------------------------
+template <bool ANY, bool STATS>
+__global__ __launch_bounds__(kBlock) void trace_queue_kernel(DevScene sc, const SrRay* __restrict__ rays, uint32_t n,
+                                                             SrHit* __restrict__ hits, uint32_t* __restrict__ occluded,
+                                                             uint32_t* __restrict__ queue_head) {
+    __shared__ int s_stack[kStackDepth * kBlock];
+    const int lane = threadIdx.x & 63;
+    int* stack = s_stack + threadIdx.x;
+    uint32_t n_queries = 0;
+    TravStats st; st.boxes = 0; st.tris = 0;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(queue_head, 64u);
+        base = __shfl(base, 0);
+        if (base >= n) break;  // wave-uniform exit: every wave reaches it once the queue is drained
+        const uint32_t i = base + lane;
+        if (i < n) {
+            const float4 ra = reinterpret_cast<const float4*>(rays)[i * 2 + 0];
+            const float4 rb = reinterpret_cast<const float4*>(rays)[i * 2 + 1];
+            TravHit h;
+            const bool found = traverse<ANY, STATS>(sc, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), ra.w, rb.w, h, stack, kBlock, st);
+            n_queries++;
+            if (ANY) occluded[i] = found ? 1u : 0u;
+            else {
+                float4 o;
+                o.x = h.t; o.y = h.u; o.z = h.v; o.w = __uint_as_float(h.gid);
+                reinterpret_cast<float4*>(hits)[i] = o;
+            }
+        }
+    }
+    flush_counter(sc.counters + (ANY ? 1 : 0), n_queries);
+    if (STATS) { flush_counter(sc.counters + 2, st.boxes); flush_counter(sc.counters + 3, st.tris); }
+}
+
+__global__ __launch_bounds__(kBlock) void shade_closest_hit_kernel(DevScene sc, const SrHit* __restrict__ hits, uint32_t n,
+                                                                   SrRayPayload* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const SrHit h = hits[i];
+    TravHit th;
+    th.t = h.t; th.u = h.u; th.v = h.v; th.gid = (h.t < 0.0f) ? 0xFFFFFFFFu : h.tri; th.prim = 0; th.inst = 0;
+    if (th.gid != 0xFFFFFFFFu) {
+        // global triangle index -> (instance, primitive): instances are few; binary search the offsets
+        uint32_t lo = 0, hi = sc.n_instances;
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sc.instances[mid].tri_offset <= th.gid) lo = mid; else hi = mid; }
+        th.inst = lo;
+        th.prim = th.gid - sc.instances[lo].tri_offset;
+    }
+    const Payload p = shade_hit(sc, th);
+    SrRayPayload o;
+    o.emission[0] = p.emission.x; o.emission[1] = p.emission.y; o.emission[2] = p.emission.z;
+    o.dist = p.dist; o.albedo_packed = p.albedo_packed; o.normal_packed = p.normal_packed;
+    o.material_info = p.material_info; o.transmission_ior_packed = p.transmission_ior_packed;
+    out[i] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-pixel passes
+// ---------------------------------------------------------------------------------------------
+struct Row4 { float x, y, z, w; };
+SRD float dot4(const float* r, float x, float y, float z, float w) { return ((r[0] * x + r[1] * y) + r[2] * z) + r[3] * w; }
+
+// K1: primary ray of pixel (px,py) (ray_gen_ris.slang:44-53 == ray_gen_final.slang:58-67)
+SRD void primary_ray(const SrMatrices& m, uint32_t px, uint32_t py, uint32_t W, uint32_t H, f3& origin, f3& dir, f2& inUV) {
+    const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
+    inUV.x = cx / (float)W; inUV.y = cy / (float)H;
+    const float dx = inUV.x * 2.0f - 1.0f, dy = inUV.y * 2.0f - 1.0f;
+    const float* vi = m.view_inverse;
+    const float* pi = m.proj_inverse;
+    origin = mk3(dot4(vi + 0, 0.0f, 0.0f, 0.0f, 1.0f), dot4(vi + 4, 0.0f, 0.0f, 0.0f, 1.0f), dot4(vi + 8, 0.0f, 0.0f, 0.0f, 1.0f));
+    const f3 target = mk3(dot4(pi + 0, dx, dy, 1.0f, 1.0f), dot4(pi + 4, dx, dy, 1.0f, 1.0f), dot4(pi + 8, dx, dy, 1.0f, 1.0f));
+    const f3 tn = norm3(target);
+    dir = mk3(dot4(vi + 0, tn.x, tn.y, tn.z, 0.0f), dot4(vi + 4, tn.x, tn.y, tn.z, 0.0f), dot4(vi + 8, tn.x, tn.y, tn.z, 0.0f));
+}
+
+struct PixelCtx {
+    const PassArgs& a;
+    int* stack;
+    uint32_t n_closest, n_any;
+    TravStats st;
+};
+
+template <bool STATS>
+SRD Payload trace_closest_shaded(PixelCtx& cx, f3 o, f3 d, float tmin, float tmax) {
+    TravHit h;
+    traverse<false, STATS>(cx.a.sc, o, d, tmin, tmax, h, cx.stack, kBlock, cx.st);
+    cx.n_closest++;
+    return shade_hit(cx.a.sc, h);
+}
+// The shadow-ray idiom of every visibility query: prd.dist preset to 1.0, the miss shader writes -1;
+// segments <= 0.002 are not traced and count as visible. Returns the resulting prd.dist.
+template <bool STATS>
+SRD float trace_shadow(PixelCtx& cx, f3 o, f3 d, float dist) {
+    if (dist > 0.002f) {
+        TravHit h;
+        cx.n_any++;
+        return traverse<true, STATS>(cx.a.sc, o, d, 0.001f, dist - 0.001f, h, cx.stack, kBlock, cx.st) ? 1.0f : -1.0f;
+    }
+    return -1.0f;
+}
+
+SRD void store_gbuffer(const PassArgs& a, uint32_t pix, float depth, f3 n, float rough, f3 diffuse, float mx, float my) {
+    a.depth_img[pix] = (uint16_t)f32_to_f16_bits(depth);
+    a.normal_img[pix] = pack_rgba8_snorm(n.x, n.y, n.z, rough);
+    a.diffuse_img[pix] = pack_b10g11r11(diffuse.x, diffuse.y, diffuse.z);
+    a.motion_vec_img[pix] = pack_half_2x16(mx, my);
+}
+SRD f3 load_normal(const PassArgs& a, uint32_t pix) {
+    const uint32_t v = a.normal_img[pix];
+    return mk3(unsnorm8(v), unsnorm8(v >> 8), unsnorm8(v >> 16));
+}
+SRD float load_depth(const PassArgs& a, uint32_t pix) { return f16_bits_to_f32(a.depth_img[pix]); }
+
+SRD void zero_reservoir(SrReservoir& r) {
+    r.light_pos[0] = r.light_pos[1] = r.light_pos[2] = 0.0f; r.w_sum = 0.0f;
+    r.light_normal[0] = r.light_normal[1] = r.light_normal[2] = 0.0f; r.M = 0.0f;
+    r.light_idx = 0u; r.W = 0.0f; r.hit_normal_packed = 0u; r.depth = 0.0f;
+}
+SRD void zero_reservoir_gi(SrReservoirGI& r) {
+    r.sample_pos[0] = r.sample_pos[1] = r.sample_pos[2] = 0.0f; r.w_sum = 0.0f;
+    r.sample_radiance[0] = r.sample_radiance[1] = r.sample_radiance[2] = 0.0f; r.M = 0.0f;
+    r.sample_normal_packed = 0u; r.W = 0.0f; r.hit_normal_packed = 0u; r.depth = 0.0f;
+}
+// 48-byte reservoir records move as three 16-byte accesses per lane
+template <typename T>
+SRD T load48(const T* p) {
+    T r;
+    const float4* s = reinterpret_cast<const float4*>(p);
+    float4* d = reinterpret_cast<float4*>(&r);
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+    return r;
+}
+template <typename T>
+SRD void store48(T* p, const T& v) {
+    float4* d = reinterpret_cast<float4*>(p);
+    const float4* s = reinterpret_cast<const float4*>(&v);
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+
+SRD f3 light_emission(const DevScene& sc, uint32_t indirection_idx) {
+    const uint32_t slot = sc.indirection[indirection_idx].blas_tri_index;
+    return ld3(sc.emissive[slot].emission);
+}
+// Uniformly sampled point on emissive triangle `idx` (ray_gen_ris.slang:191-210,346-362;
+// ray_gen_final.slang:330-351). The random draws stay at the call sites: their order is semantic.
+struct LightTri { f3 wv0, wv1, wv2, emission; };
+SRD LightTri fetch_light(const DevScene& sc, uint32_t idx) {
+    const SrEmissiveIndirectionEntry e = sc.indirection[idx];
+    const SrEmissiveTriangle* lt = sc.emissive + e.blas_tri_index;
+    const float* xf = sc.transforms[e.entity_id].m;
+    LightTri r;
+    r.wv0 = transform_point(xf, ld3(lt->v0));
+    r.wv1 = transform_point(xf, ld3(lt->v1));
+    r.wv2 = transform_point(xf, ld3(lt->v2));
+    r.emission = ld3(lt->emission);
+    return r;
+}
+
+// Map this thread to its pixel. Returns false for threads outside the image / tile.
+SRD bool thread_pixel(const PassArgs& a, uint32_t& px, uint32_t& py) {
+    const uint32_t b = blockIdx.x;
+    const uint32_t tile = (b & 7u) * a.tiles_per_xcd + (b >> 3);
+    if (tile >= a.tiles_x * a.tiles_y) return false;
+    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    px = tx * 16u + (w & 1u) * 8u + (l & 7u);
+    py = a.y0 + ty * 16u + (w >> 1) * 8u + (l >> 3);
+    return px < a.width && py < a.y1;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
+    __shared__ int s_stack[kStackDepth * kBlock];
+    PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
+    const DevScene& sc = a.sc;
+    uint32_t px = 0, py = 0;
+    const bool active = thread_pixel(a, px, py);
+    if (active) {
+        const uint32_t W = a.width, H = a.height;
+        const uint32_t pix = py * W + px;
+        const uint32_t cur_buf = a.frame_count & 1u, hist_buf = cur_buf ^ 1u;
+        SrReservoir* reservoir_cur = a.reservoirs[cur_buf];
+        const SrReservoir* reservoir_hist = a.reservoirs[hist_buf];
+        SrReservoirGI* reservoir_gi_cur = a.reservoirs_gi[cur_buf];
+        const SrReservoirGI* reservoir_gi_hist = a.reservoirs_gi[hist_buf];
+        const float* pvp = a.mats.prev_view_proj;
+
+        uint32_t rng = init_rng(px, py, a.frame_count, W);
+        f3 origin, direction; f2 inUV;
+        primary_ray(a.mats, px, py, W, H, origin, direction, inUV);
+        f3 rayOrigin = origin, rayDir = direction;
+
+        Payload prd;
+        f3 hitPos = splat(0.0f), hit_normal = splat(0.0f), hit_albedo = splat(0.0f);
+        float roughness = 0.5f, metallic = 0.0f;
+        f3 V_view = splat(0.0f);
+        float prev_u = -1.0f, prev_v = -1.0f;
+        bool prev_valid = false, found_diffuse_surface = false;
+        float virtual_distance = 0.0f;
+
+        for (uint32_t vb = 0; vb < a.cfg.virtual_bounces; vb++) {
+            prd = trace_closest_shaded<STATS>(cx, rayOrigin, rayDir, 0.001f, 10000.0f);
+            if (prd.dist < 0.0f) break;
+            hitPos = rayOrigin + rayDir * prd.dist;
+            hit_normal = unpack_normal(prd.normal_packed);
+            hit_albedo = unpack_unorm_rgb(prd.albedo_packed);
+            const f2 mat_info = unpack_half_2x16(prd.material_info);
+            roughness = fmaxf(mat_info.x, 0.01f);
+            metallic = clampf(mat_info.y, 0.0f, 1.0f);
+            const f2 trans_ior = unpack_half_2x16(prd.transmission_ior_packed);
+            const float transmission = trans_ior.x;
+            V_view = -rayDir;
+            virtual_distance += prd.dist;
+            if (transmission > 0.5f) {
+                const float ior = fmaxf(trans_ior.y, 1.0f);
+                const bool is_inside = dot3(rayDir, hit_normal) > 0.0f;
+                const f3 N = is_inside ? -hit_normal : hit_normal;
+                const float eta = is_inside ? (ior / 1.0f) : (1.0f / ior);
+                const float cos_theta = fminf(dot3(-rayDir, N), 1.0f);
+                float R0 = (1.0f - eta) / (1.0f + eta);
+                R0 = R0 * R0;
+                float fresnel = R0 + (1.0f - R0) * pow5f(1.0f - cos_theta);
+                const f3 refracted = refract3(rayDir, N, eta);
+                if (len3(refracted) < 0.01f) fresnel = 1.0f;
+                if (rnd(rng) < fresnel) rayDir = reflect3(rayDir, N);
+                else rayDir = refracted;
+                rayOrigin = hitPos + rayDir * 0.001f;
+            } else if (metallic > 0.9f && roughness < 0.1f) {
+                rayOrigin = hitPos + hit_normal * 0.001f;
+                rayDir = reflect3(rayDir, hit_normal);
+            } else {
+                const f3 vwp = origin + direction * virtual_distance;
+                const float clip_x = dot4(pvp + 0, vwp.x, vwp.y, vwp.z, 1.0f);
+                const float clip_y = dot4(pvp + 4, vwp.x, vwp.y, vwp.z, 1.0f);
+                const float clip_w = dot4(pvp + 12, vwp.x, vwp.y, vwp.z, 1.0f);
+                prev_valid = clip_w > 0.01f;
+                if (prev_valid) {
+                    const float iw = 1.0f / clip_w;
+                    prev_u = (clip_x * iw) * 0.5f + 0.5f;
+                    prev_v = (clip_y * iw) * 0.5f + 0.5f;
+                    prev_valid = (prev_u >= 0.0f && prev_v >= 0.0f) && (prev_u < 1.0f && prev_v < 1.0f);
+                }
+                const float mvx = prev_valid ? (inUV.x - prev_u) : (inUV.x + 2.0f);
+                const float mvy = prev_valid ? (inUV.y - prev_v) : (inUV.y + 2.0f);
+                const f3 denoiser_albedo = lerp3(hit_albedo, splat(1.0f), metallic);
+                store_gbuffer(a, pix, virtual_distance, hit_normal, roughness, denoiser_albedo, mvx, mvy);
+                found_diffuse_surface = true;
+                break;
+            }
+        }
+
+        if (!found_diffuse_surface) {
+            store_gbuffer(a, pix, 100000.0f, splat(0.0f), 0.0f, splat(0.0f), 0.0f, 0.0f);
+            SrReservoir empty; zero_reservoir(empty);
+            store48(reservoir_cur + pix, empty);
+        } else {
+            SrReservoir current_r; zero_reservoir(current_r);
+            const uint32_t num_lights = sc.num_lights;
+            if (num_lights > 0 && roughness > 0.2f) {
+                for (uint32_t i = 0; i < a.cfg.ris_candidates; i++) {
+                    uint32_t cand_idx = (uint32_t)(rnd(rng) * (float)num_lights);
+                    if (cand_idx > num_lights - 1) cand_idx = num_lights - 1;
+                    const LightTri lt = fetch_light(sc, cand_idx);
+                    const f3 edge1 = lt.wv1 - lt.wv0, edge2 = lt.wv2 - lt.wv0;
+                    const float cand_area = 0.5f * len3(cross3(edge1, edge2));
+                    const float sqr1 = sqrtf(rnd(rng));
+                    const float u = 1.0f - sqr1;
+                    const float v = rnd(rng) * sqr1;
+                    const float w = 1.0f - u - v;
+                    const f3 cand_pos = lt.wv0 * u + lt.wv1 * v + lt.wv2 * w;
+                    const f3 cand_normal = norm3(cross3(lt.wv1 - lt.wv0, lt.wv2 - lt.wv0));
+                    const f3 f_y = eval_unshadowed_light(hitPos, hit_normal, V_view, hit_albedo, roughness, metallic, lt.emission, cand_pos, cand_normal);
+                    const float p_hat = maxc(f_y);
+                    const float p_y = 1.0f / fmaxf((float)num_lights * cand_area, 0.0001f);
+                    current_r.w_sum += (p_hat / p_y);
+                    current_r.M += 1.0f;
+                    if (rnd(rng) < ((p_hat / p_y) / fmaxf(current_r.w_sum, 0.0001f))) {
+                        current_r.light_idx = cand_idx;
+                        st3(current_r.light_pos, cand_pos);
+                        st3(current_r.light_normal, cand_normal);
+                    }
+                }
+                if (current_r.w_sum > 0.0f) {
+                    const f3 fw = eval_unshadowed_light(hitPos, hit_normal, V_view, hit_albedo, roughness, metallic,
+                                                        light_emission(sc, current_r.light_idx), ld3(current_r.light_pos), ld3(current_r.light_normal));
+                    current_r.W = current_r.w_sum / fmaxf(current_r.M * maxc(fw), 0.0001f);
+                }
+                if (a.frame_count > 0 && prev_valid) {
+                    const float ppx = prev_u * (float)W, ppy = prev_v * (float)H;
+                    const float j0 = rnd(rng), j1 = rnd(rng);
+                    const int pcx = (int)(ppx + (j0 - 0.5f)), pcy = (int)(ppy + (j1 - 0.5f));
+                    if (pcx >= 0 && pcy >= 0 && pcx < (int)W && pcy < (int)H) {
+                        SrReservoir history_r = load48(reservoir_hist + ((uint32_t)pcy * W + (uint32_t)pcx));
+                        history_r.M = fminf(history_r.M, 10.0f);
+                        history_r.W = fminf(history_r.W, 20.0f);
+                        const f3 hist_normal = unpack_normal(history_r.hit_normal_packed);
+                        const float normal_conf_di = smoothstepf(0.9f, 0.99f, dot3(hit_normal, hist_normal));
+                        const float depth_diff_di = fabsf(virtual_distance - history_r.depth) / fmaxf(virtual_distance, 1e-4f);
+                        const float depth_conf_di = 1.0f - smoothstepf(0.05f, 0.20f, depth_diff_di);
+                        const float conf_di = normal_conf_di * depth_conf_di;
+                        history_r.M *= conf_di;
+                        if (history_r.W > 0.0f) {
+                            history_r.light_idx = history_r.light_idx < num_lights - 1 ? history_r.light_idx : num_lights - 1;
+                            const f3 fh = eval_unshadowed_light(hitPos, hit_normal, V_view, hit_albedo, roughness, metallic,
+                                                                light_emission(sc, history_r.light_idx), ld3(history_r.light_pos), ld3(history_r.light_normal));
+                            const float hist_rand = rnd(rng);
+                            merge_reservoirs(current_r, history_r, maxc(fh), hist_rand);
+                            const f3 fm = eval_unshadowed_light(hitPos, hit_normal, V_view, hit_albedo, roughness, metallic,
+                                                                light_emission(sc, current_r.light_idx), ld3(current_r.light_pos), ld3(current_r.light_normal));
+                            current_r.W = current_r.w_sum / fmaxf(current_r.M * maxc(fm), 0.0001f);
+                        }
+                    }
+                }
+            }
+            if (current_r.W > 0.0f) {
+                f3 vis_dir = ld3(current_r.light_pos) - hitPos;
+                const float vis_dist = fmaxf(len3(vis_dir), 0.0001f);
+                vis_dir = vis_dir / vis_dist;
+                if (dot3(hit_normal, vis_dir) <= 0.0f) current_r.W = 0.0f;
+                else {
+                    prd.dist = trace_shadow<STATS>(cx, hitPos + hit_normal * 0.001f, vis_dir, vis_dist);
+                    if (prd.dist >= 0.0f) current_r.W = 0.0f;
+                }
+            }
+            current_r.hit_normal_packed = pack_normal(hit_normal);
+            current_r.depth = virtual_distance;
+            store48(reservoir_cur + pix, current_r);
+
+            // Phase 3: ReSTIR GI initial sample
+            SrReservoirGI gi; zero_reservoir_gi(gi);
+            const float gr1 = rnd(rng), gr2 = rnd(rng);
+            const f3 gi_dir = get_random_bounce(hit_normal, gr1, gr2);
+            const float gi_NdotL = fmaxf(dot3(hit_normal, gi_dir), 0.0f);
+            if (gi_NdotL > 0.0f) {
+                const f3 gi_origin = hitPos + hit_normal * 0.001f;
+                prd = trace_closest_shaded<STATS>(cx, gi_origin, gi_dir, 0.001f, 10000.0f);
+                f3 sample_pos = splat(0.0f), sample_normal = splat(0.0f), sample_radiance = splat(0.0f);
+                if (prd.dist > 0.0f) {
+                    sample_pos = gi_origin + gi_dir * prd.dist;
+                    sample_normal = unpack_normal(prd.normal_packed);
+                    const f3 x2_albedo = unpack_unorm_rgb(prd.albedo_packed);
+                    sample_radiance = prd.emission;
+                    if (num_lights > 0) {
+                        uint32_t nee_idx = (uint32_t)(rnd(rng) * (float)num_lights);
+                        if (nee_idx > num_lights - 1) nee_idx = num_lights - 1;
+                        const LightTri lt = fetch_light(sc, nee_idx);
+                        const float sq = sqrtf(rnd(rng));
+                        const float nu = 1.0f - sq;
+                        const float nv = rnd(rng) * sq;
+                        const float nw = 1.0f - nu - nv;
+                        const f3 nee_pos = lt.wv0 * nu + lt.wv1 * nv + lt.wv2 * nw;
+                        const f3 ncr = cross3(lt.wv1 - lt.wv0, lt.wv2 - lt.wv0);
+                        const f3 nee_normal = norm3(ncr);
+                        const float nee_area = 0.5f * len3(ncr);
+                        f3 to_light = nee_pos - sample_pos;
+                        const float nee_dist = fmaxf(len3(to_light), 0.0001f);
+                        to_light = to_light / nee_dist;
+                        const float nee_cos_surf = fmaxf(dot3(sample_normal, to_light), 0.0f);
+                        const float nee_cos_light = fmaxf(dot3(nee_normal, -to_light), 0.0f);
+                        if (nee_cos_surf > 0.0f && nee_cos_light > 0.0f) {
+                            prd.dist = trace_shadow<STATS>(cx, sample_pos + sample_normal * 0.001f, to_light, nee_dist);
+                            if (prd.dist < 0.0f) {
+                                const float nee_pdf_sa = (nee_dist * nee_dist) / fmaxf(nee_cos_light * nee_area * (float)num_lights, 0.0001f);
+                                sample_radiance = sample_radiance + (lt.emission * x2_albedo * nee_cos_surf) / (nee_pdf_sa * 3.14159f);
+                            }
+                        }
+                    }
+                }
+                sample_radiance = vmin(sample_radiance, splat(5.0f));
+                const float p_hat = gi_target_pdf(hitPos, hit_normal, hit_albedo, metallic, sample_pos, sample_radiance);
+                const float pdf = gi_NdotL / 3.14159f;
+                gi.M = 1.0f;
+                gi.w_sum = (pdf > 0.0f) ? (p_hat / pdf) : 0.0f;
+                gi.W = (p_hat > 0.0f) ? (gi.w_sum / (gi.M * p_hat)) : 0.0f;
+                st3(gi.sample_pos, sample_pos);
+                gi.sample_normal_packed = pack_normal(sample_normal);
+                st3(gi.sample_radiance, sample_radiance);
+            }
+            if (a.frame_count > 0 && prev_valid) {
+                const float ppx = prev_u * (float)W, ppy = prev_v * (float)H;
+                const float j0 = rnd(rng), j1 = rnd(rng);
+                const int gx = (int)(ppx + (j0 - 0.5f)), gy = (int)(ppy + (j1 - 0.5f));
+                if (gx >= 0 && gy >= 0 && gx < (int)W && gy < (int)H) {
+                    SrReservoirGI hgi = load48(reservoir_gi_hist + ((uint32_t)gy * W + (uint32_t)gx));
+                    const f3 gi_hist_normal = unpack_normal(hgi.hit_normal_packed);
+                    const float normal_conf = smoothstepf(0.8f, 0.95f, dot3(hit_normal, gi_hist_normal));
+                    const float depth_diff = fabsf(virtual_distance - hgi.depth) / fmaxf(virtual_distance, 1e-4f);
+                    const float depth_conf = 1.0f - smoothstepf(0.05f, 0.20f, depth_diff);
+                    const float conf = normal_conf * depth_conf;
+                    hgi.M = fminf(hgi.M, 12.0f) * conf;
+                    hgi.W = fminf(hgi.W, 10.0f);
+                    if (hgi.W > 0.0f && hgi.M > 0.0f) {
+                        const float p_hat_hist = gi_target_pdf(hitPos, hit_normal, hit_albedo, metallic, ld3(hgi.sample_pos), ld3(hgi.sample_radiance));
+                        const float mr = rnd(rng);
+                        merge_reservoirs_gi(gi, hgi, p_hat_hist, 1.0f, mr);
+                        const float p_hat_merged = gi_target_pdf(hitPos, hit_normal, hit_albedo, metallic, ld3(gi.sample_pos), ld3(gi.sample_radiance));
+                        gi.W = (p_hat_merged > 1e-6f) ? (gi.w_sum / (gi.M * p_hat_merged)) : 0.0f;
+                    }
+                }
+            }
+            gi.hit_normal_packed = pack_normal(hit_normal);
+            gi.depth = virtual_distance;
+            store48(reservoir_gi_cur + pix, gi);
+        }
+    }
+    flush_counter(sc.counters + 0, cx.n_closest);
+    flush_counter(sc.counters + 1, cx.n_any);
+    if (STATS) { flush_counter(sc.counters + 2, cx.st.boxes); flush_counter(sc.counters + 3, cx.st.tris); }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
+    __shared__ int s_stack[kStackDepth * kBlock];
+    PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
+    const DevScene& sc = a.sc;
+    uint32_t px = 0, py = 0;
+    const bool active = thread_pixel(a, px, py);
+    if (active) {
+        const uint32_t W = a.width, H = a.height;
+        const uint32_t pix = py * W + px;
+        const int ipx = (int)px, ipy = (int)py;
+        const uint32_t cur_buf = a.frame_count & 1u;
+        const SrReservoir* reservoir_cur = a.reservoirs[cur_buf];
+        const SrReservoirGI* reservoir_gi_cur = a.reservoirs_gi[cur_buf];
+
+        uint32_t rng = init_rng(px, py, a.frame_count, W);
+        f3 total_radiance = splat(0.0f);
+        const int BOUNCES = (int)a.cfg.max_bounces;
+        const int SHADOW_BOUNCES = (int)a.cfg.shadow_bounces;
+        const int bw = (int)a.blue_noise_w, bh = (int)a.blue_noise_h;
+        const int n1x = ipx % bw, n1y = ipy % bh;
+        const int n2x = (ipx + 47) % bw, n2y = (ipy + 71) % bh;
+        const float bn_1 = (float)a.blue_noise_tex[((size_t)n1y * bw + n1x) * 4] / 255.0f;
+        const float bn_2 = (float)a.blue_noise_tex[((size_t)n2y * bw + n2x) * 4] / 255.0f;
+        const uint32_t num_lights = sc.num_lights;
+        Payload prd;
+
+        {   // SAMPLES = 1 (ray_gen_final.slang:40)
+            f3 origin, rayDir0; f2 inUV;
+            primary_ray(a.mats, px, py, W, H, origin, rayDir0, inUV);
+            f3 rayOrigin = origin, rayDir = rayDir0;
+            f3 throughput = splat(1.0f), radiance = splat(0.0f);
+            bool restir_evaluated = (a.cfg.enable_restir == 0);
+            bool prev_did_nee = false;
+
+            for (int bounce = 0; bounce < BOUNCES; bounce++) {
+                prd = trace_closest_shaded<STATS>(cx, rayOrigin, rayDir, 0.001f, 10000.0f);
+                if (prd.dist < 0.0f) break;
+                const f3 hit_normal = unpack_normal(prd.normal_packed);
+                const f3 hit_albedo = unpack_unorm_rgb(prd.albedo_packed);
+                const f3 hitPos = rayOrigin + rayDir * prd.dist;
+                const f3 V_view = -rayDir;
+                const f2 mat_info = unpack_half_2x16(prd.material_info);
+                const float roughness = fmaxf(mat_info.x, 0.01f);
+                const float metallic = clampf(mat_info.y, 0.0f, 1.0f);
+                const f2 trans_ior = unpack_half_2x16(prd.transmission_ior_packed);
+                const float transmission = trans_ior.x;
+                const float ior = fmaxf(trans_ior.y, 1.0f);
+                if (!prev_did_nee) radiance = radiance + prd.emission * throughput;
+                prev_did_nee = false;
+                const float brightness = maxc(prd.emission);
+                if (brightness > 1.0f) break;
+
+                if (transmission > 0.5f) {
+                    const bool is_inside = dot3(rayDir, hit_normal) > 0.0f;
+                    const f3 N = is_inside ? -hit_normal : hit_normal;
+                    const float eta = is_inside ? (ior / 1.0f) : (1.0f / ior);
+                    const float cos_theta = fminf(dot3(-rayDir, N), 1.0f);
+                    float R0 = (1.0f - eta) / (1.0f + eta);
+                    R0 = R0 * R0;
+                    float fresnel = R0 + (1.0f - R0) * pow5f(1.0f - cos_theta);
+                    const f3 refracted = refract3(rayDir, N, eta);
+                    if (len3(refracted) < 0.01f) fresnel = 1.0f;
+                    if (rnd(rng) < fresnel) rayDir = reflect3(rayDir, N);
+                    else {
+                        rayDir = refracted;
+                        if (is_inside) {
+                            const f3 absorption = 1.0f - hit_albedo;
+                            const f3 e = -absorption * prd.dist * 5.0f;
+                            throughput = throughput * mk3(exp_pinned(e.x), exp_pinned(e.y), exp_pinned(e.z));
+                        } else throughput = throughput * hit_albedo;
+                    }
+                    rayOrigin = hitPos + rayDir * 0.001f;
+                    continue;
+                }
+
+                if (num_lights > 0 && bounce < SHADOW_BOUNCES) {
+                    if (!restir_evaluated && roughness > 0.2f) {
+                        restir_evaluated = true;
+                        SrReservoir center_r = load48(reservoir_cur + pix);
+                        SrReservoir spatial_r; zero_reservoir(spatial_r);
+                        if (center_r.W > 0.0f && center_r.light_idx < num_lights) {
+                            center_r.light_idx = center_r.light_idx < num_lights - 1 ? center_r.light_idx : num_lights - 1;
+                            const f3 fc = eval_unshadowed_light(hitPos, hit_normal, V_view, hit_albedo, roughness, metallic,
+                                                                light_emission(sc, center_r.light_idx), ld3(center_r.light_pos), ld3(center_r.light_normal));
+                            const float cr = rnd(rng);
+                            merge_reservoirs(spatial_r, center_r, maxc(fc), cr);
+                        }
+                        const float current_depth = len3(hitPos - origin);
+                        for (int s = 0; s < 5; s++) {  // SPATIAL_SAMPLES = 5, SPATIAL_RADIUS = 30
+                            const float angle = rnd(rng) * 2.0f * 3.14159f;
+                            const float radius = sqrtf(rnd(rng)) * 30.0f;
+                            float sa, ca; sincos_pinned(angle, sa, ca);
+                            const int ncx = ipx + (int)(ca * radius), ncy = ipy + (int)(sa * radius);
+                            if (ncx < 0 || ncy < 0 || ncx >= (int)W || ncy >= (int)H) continue;
+                            const uint32_t pi_n = (uint32_t)ncy * W + (uint32_t)ncx;
+                            const f3 neighbor_normal = load_normal(a, pi_n);
+                            const float neighbor_depth = load_depth(a, pi_n);
+                            if (dot3(hit_normal, neighbor_normal) < 0.9f) continue;
+                            if (fabsf(current_depth - neighbor_depth) > 0.1f * current_depth) continue;
+                            SrReservoir nr = load48(reservoir_cur + pi_n);
+                            nr.W = fminf(nr.W, 20.0f);
+                            nr.M = fminf(nr.M, 10.0f);
+                            if (nr.W > 0.0f && nr.light_idx < num_lights) {
+                                nr.light_idx = nr.light_idx < num_lights - 1 ? nr.light_idx : num_lights - 1;
+                                const f3 fn = eval_unshadowed_light(hitPos, hit_normal, V_view, hit_albedo, roughness, metallic,
+                                                                    light_emission(sc, nr.light_idx), ld3(nr.light_pos), ld3(nr.light_normal));
+                                const float nrnd = rnd(rng);
+                                merge_reservoirs(spatial_r, nr, maxc(fn), nrnd);
+                            }
+                        }
+                        if (spatial_r.w_sum > 0.0f) {
+                            const f3 f_y_winner = eval_unshadowed_light(hitPos, hit_normal, V_view, hit_albedo, roughness, metallic,
+                                                                        light_emission(sc, spatial_r.light_idx), ld3(spatial_r.light_pos), ld3(spatial_r.light_normal));
+                            spatial_r.W = spatial_r.w_sum / fmaxf(spatial_r.M * maxc(f_y_winner), 1e-3f);
+                            spatial_r.W = fminf(spatial_r.W, 50.0f);
+                            f3 shadow_dir = ld3(spatial_r.light_pos) - hitPos;
+                            const float shadow_dist = fmaxf(len3(shadow_dir), 0.0001f);
+                            shadow_dir = shadow_dir / shadow_dist;
+                            if (dot3(hit_normal, shadow_dir) > 0.0f) {
+                                prd.dist = trace_shadow<STATS>(cx, hitPos, shadow_dir, shadow_dist);
+                                if (prd.dist < 0.0f) radiance = radiance + f_y_winner * throughput * spatial_r.W;
+                                prev_did_nee = true;
+                            }
+                        }
+                        // ReSTIR GI spatial reuse
+                        SrReservoirGI combined = load48(reservoir_gi_cur + pix);
+                        const float gi_current_depth = len3(hitPos - origin);
+                        for (int s = 0; s < 3; s++) {  // GI_SPATIAL_SAMPLES = 3, GI_SPATIAL_RADIUS = 20
+                            const float gi_angle = rnd(rng) * 2.0f * 3.14159f;
+                            const float gi_radius = sqrtf(rnd(rng)) * 20.0f;
+                            float sa, ca; sincos_pinned(gi_angle, sa, ca);
+                            const int ncx = ipx + (int)(ca * gi_radius), ncy = ipy + (int)(sa * gi_radius);
+                            if (ncx == ipx && ncy == ipy) continue;
+                            if (ncx < 0 || ncy < 0 || ncx >= (int)W || ncy >= (int)H) continue;
+                            const uint32_t pi_nn = (uint32_t)ncy * W + (uint32_t)ncx;
+                            const f3 neighbor_normal = load_normal(a, pi_nn);
+                            const float neighbor_depth = load_depth(a, pi_nn);
+                            if (dot3(hit_normal, neighbor_normal) < 0.9f) continue;
+                            if (fabsf(gi_current_depth - neighbor_depth) > 0.1f * gi_current_depth) continue;
+                            SrReservoirGI nr = load48(reservoir_gi_cur + pi_nn);
+                            if (nr.W <= 0.0f) continue;
+                            nr.W = fminf(nr.W, 10.0f);
+                            nr.M = fminf(nr.M, 10.0f);
+                            f3 n_origin, n_dir; f2 n_uv;
+                            primary_ray(a.mats, (uint32_t)ncx, (uint32_t)ncy, W, H, n_origin, n_dir, n_uv);
+                            const f3 neighbor_x1 = origin + n_dir * neighbor_depth;
+                            const f3 nsp = ld3(nr.sample_pos);
+                            const f3 w_new = nsp - hitPos;
+                            const f3 w_old = nsp - neighbor_x1;
+                            const float d_new = fmaxf(len3(w_new), 1e-4f);
+                            const float d_old = fmaxf(len3(w_old), 1e-4f);
+                            const f3 n_x2 = unpack_normal(nr.sample_normal_packed);
+                            const float cos_new = fmaxf(dot3(n_x2, (-w_new) / d_new), 0.0f);
+                            const float cos_old = fmaxf(dot3(n_x2, (-w_old) / d_old), 0.0f);
+                            if (cos_new <= 0.0f || cos_old <= 0.0f) continue;
+                            float jacobian = (cos_new * d_old * d_old) / fmaxf(cos_old * d_new * d_new, 1e-4f);
+                            jacobian = clampf(jacobian, 0.0f, 10.0f);
+                            const f3 gi_spatial_dir = w_new / d_new;
+                            if (dot3(hit_normal, gi_spatial_dir) <= 0.0f) continue;
+                            prd.dist = trace_shadow<STATS>(cx, hitPos, gi_spatial_dir, d_new);
+                            if (prd.dist >= 0.0f) continue;
+                            const float p_hat_neighbor = gi_target_pdf(hitPos, hit_normal, hit_albedo, metallic, nsp, ld3(nr.sample_radiance));
+                            const float gr = rnd(rng);
+                            merge_reservoirs_gi(combined, nr, p_hat_neighbor, jacobian, gr);
+                        }
+                        const float p_hat_final = gi_target_pdf(hitPos, hit_normal, hit_albedo, metallic, ld3(combined.sample_pos), ld3(combined.sample_radiance));
+                        combined.W = (p_hat_final > 1e-3f) ? (combined.w_sum / fmaxf(combined.M, 1.0f) / p_hat_final) : 0.0f;
+                        combined.W = fminf(combined.W, 20.0f);
+                        if (combined.W > 0.0f) {
+                            f3 gi_x2_dir = ld3(combined.sample_pos) - hitPos;
+                            const float gi_x2_dist = fmaxf(len3(gi_x2_dir), 0.0001f);
+                            gi_x2_dir = gi_x2_dir / gi_x2_dist;
+                            const float gi_NdotL = fmaxf(dot3(hit_normal, gi_x2_dir), 0.0f);
+                            if (gi_NdotL > 0.0f) {
+                                prd.dist = trace_shadow<STATS>(cx, hitPos, gi_x2_dir, gi_x2_dist);
+                                if (prd.dist < 0.0f) {
+                                    const f3 gi_f_diffuse = hit_albedo * (1.0f - metallic) / 3.14159f;
+                                    radiance = radiance + ld3(combined.sample_radiance) * gi_f_diffuse * gi_NdotL * combined.W * throughput;
+                                }
+                            }
+                        }
+                        break;
+                    } else if (restir_evaluated && roughness > 0.2f) {
+                        uint32_t light_idx = (uint32_t)(rnd(rng) * (float)num_lights);
+                        if (light_idx > num_lights - 1) light_idx = num_lights - 1;
+                        const LightTri lt = fetch_light(sc, light_idx);
+                        const f3 edge1 = lt.wv1 - lt.wv0, edge2 = lt.wv2 - lt.wv0;
+                        const f3 lcr = cross3(edge1, edge2);
+                        const float light_area = 0.5f * len3(lcr);
+                        const float r1_nee = rnd(rng);
+                        const float r2_nee = rnd(rng);
+                        const float sqr1 = sqrtf(r1_nee);
+                        const float u = 1.0f - sqr1;
+                        const float v = r2_nee * sqr1;
+                        const float w = 1.0f - u - v;
+                        const f3 light_pos = lt.wv0 * u + lt.wv1 * v + lt.wv2 * w;
+                        const f3 light_normal = norm3(lcr);
+                        f3 shadow_ray_dir = light_pos - hitPos;
+                        const float light_dist = len3(shadow_ray_dir);
+                        shadow_ray_dir = shadow_ray_dir / light_dist;
+                        const float cos_theta_light = fmaxf(dot3(light_normal, -shadow_ray_dir), 0.0f);
+                        const float cos_theta_surface = fmaxf(dot3(hit_normal, shadow_ray_dir), 0.0f);
+                        if (cos_theta_light > 0.0f && cos_theta_surface > 0.0f) {
+                            prd.dist = trace_shadow<STATS>(cx, hitPos, shadow_ray_dir, light_dist);
+                            if (prd.dist < 0.0f) {
+                                const float solid_angle_pdf = (light_dist * light_dist) / fmaxf(cos_theta_light * light_area * (float)num_lights, 1e-4f);
+                                const f3 nee_contrib = (lt.emission * hit_albedo * throughput * cos_theta_surface) / (solid_angle_pdf * 3.14159f);
+                                radiance = radiance + vmin(nee_contrib, splat(5.0f));
+                            }
+                            prev_did_nee = true;
+                        }
+                    }
+                }
+
+                // BRDF bounce
+                const f3 N = hit_normal;
+                const f3 F0 = lerp3(splat(0.04f), hit_albedo, metallic);
+                const float cos_theta = fmaxf(dot3(N, V_view), 0.0f);
+                const f3 F = F0 + (1.0f - F0) * pow5f(clampf(1.0f - cos_theta, 0.0f, 1.0f));
+                const float p_specular = clampf(maxc(F), 0.05f, 1.0f);
+                float r1, r2;
+                if (bounce == 0) {
+                    r1 = fracf(bn_1 + (float)(a.frame_count % 1024u) * 0.75487766f);
+                    r2 = fracf(bn_2 + (float)(a.frame_count % 1024u) * 0.56984029f);
+                } else {
+                    r1 = rnd(rng);
+                    r2 = rnd(rng);
+                }
+                if (rnd(rng) < p_specular) {
+                    const f3 Hh = sample_ggx_vndf(N, V_view, roughness, r1, r2);
+                    rayDir = reflect3(-V_view, Hh);
+                    if (dot3(N, rayDir) <= 0.0f) {
+                        rayDir = get_random_bounce(N, r1, r2);
+                        throughput = throughput * (hit_albedo * (1.0f - metallic) * (1.0f - F) / (1.0f - p_specular));
+                    } else {
+                        const float NdotL_b = fmaxf(dot3(N, rayDir), 0.001f);
+                        const float alpha_b = roughness * roughness;
+                        const float G1_L = smith_g1_ggx(NdotL_b, alpha_b);
+                        throughput = throughput * ((F * G1_L) / p_specular);
+                    }
+                } else {
+                    rayDir = get_random_bounce(N, r1, r2);
+                    throughput = throughput * (hit_albedo * (1.0f - metallic) * (1.0f - F) / (1.0f - p_specular));
+                }
+                const float p = maxc(throughput);
+                if (p < 0.001f) break;
+                if (bounce > 2) {
+                    if (rnd(rng) > p) break;
+                    throughput = throughput / p;
+                }
+                rayOrigin = hitPos + hit_normal * 0.001f;
+            }
+            total_radiance = total_radiance + radiance;
+            total_radiance = vmin(total_radiance, splat(10.0f));
+        }
+        const f3 color = total_radiance / 1.0f;  // / float(SAMPLES)
+        float4 o;
+        o.x = color.x; o.y = color.y; o.z = color.z; o.w = 1.0f;
+        reinterpret_cast<float4*>(a.raw_color)[pix] = o;
+    }
+    flush_counter(sc.counters + 0, cx.n_closest);
+    flush_counter(sc.counters + 1, cx.n_any);
+    if (STATS) { flush_counter(sc.counters + 2, cx.st.boxes); flush_counter(sc.counters + 3, cx.st.tris); }
+}
+
+}  // namespace srd
+
+// ---------------------------------------------------------------------------------------------
+// Host-side launchers (called from api.cpp)
+// ---------------------------------------------------------------------------------------------
+using namespace srd;
+
+int srk_launch_trace(const DevScene& sc, const SrRay* rays, uint32_t n, SrHit* hits, uint32_t* occluded,
+                     uint32_t* queue_head, int any, int stats, int n_blocks, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(queue_head, 0, 16, stream);
+    if (e != hipSuccess) return (int)e;
+    if (n == 0) return 0;
+    dim3 grid(n_blocks), block(kBlock);
+    if (any) {
+        if (stats) trace_queue_kernel<true, true><<<grid, block, 0, stream>>>(sc, rays, n, hits, occluded, queue_head);
+        else trace_queue_kernel<true, false><<<grid, block, 0, stream>>>(sc, rays, n, hits, occluded, queue_head);
+    } else {
+        if (stats) trace_queue_kernel<false, true><<<grid, block, 0, stream>>>(sc, rays, n, hits, occluded, queue_head);
+        else trace_queue_kernel<false, false><<<grid, block, 0, stream>>>(sc, rays, n, hits, occluded, queue_head);
+    }
+    return (int)hipGetLastError();
+}
+
+int srk_launch_shade(const DevScene& sc, const SrHit* hits, uint32_t n, SrRayPayload* out, hipStream_t stream) {
+    if (n == 0) return 0;
+    shade_closest_hit_kernel<<<dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream>>>(sc, hits, n, out);
+    return (int)hipGetLastError();
+}
+
+int srk_launch_pass(const PassArgs& args, int which, int stats, hipStream_t stream) {
+    const uint32_t n_tiles = args.tiles_x * args.tiles_y;
+    if (n_tiles == 0) return 0;
+    dim3 grid(args.tiles_per_xcd * 8), block(kBlock);
+    if (which == 0) {
+        if (stats) ris_kernel<true><<<grid, block, 0, stream>>>(args);
+        else ris_kernel<false><<<grid, block, 0, stream>>>(args);
+    } else {
+        if (stats) final_kernel<true><<<grid, block, 0, stream>>>(args);
+        else final_kernel<false><<<grid, block, 0, stream>>>(args);
+    }
+    return (int)hipGetLastError();
+}

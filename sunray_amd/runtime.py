@@ -1,0 +1,243 @@
+"""Thin Python harness over the C ABI (include/sunray_hip.h) for tests and bench.py.
+
+PyTorch is used only as plumbing: device memory (torch tensors as frame buffers), the current HIP
+stream, and torch.distributed for the multi-GPU gather. Every compute call goes through
+libsunray_hip.so; there is no CPU or torch fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from ._lib import SunrayError, check, lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def camera_matrices(pos, target, fov_y, width, height, prev_view_proj=None):
+    """Camera::as_matrices + transposed upload (camera.rs:33-63, lib.rs:1017-1048). Host only."""
+    m = abi.SrMatrices()
+    prev = None
+    if prev_view_proj is not None:
+        prev = (C.c_float * 16)(*[float(x) for x in prev_view_proj])
+    check(lib().sr_camera_matrices(_f3(pos), _f3(target), C.c_float(fov_y), C.c_uint32(width), C.c_uint32(height), prev, C.byref(m)))
+    return m
+
+
+def material_new(base_color, metallic, roughness, emissive_factor, emissive_strength, transmission, ior):
+    m = np.zeros((), dtype=abi.MATERIAL)
+    check(lib().sr_material_new((C.c_float * 4)(*base_color), C.c_float(metallic), C.c_float(roughness), _f3(emissive_factor),
+                                C.c_float(emissive_strength), C.c_float(transmission), C.c_float(ior), _p(m)))
+    return m
+
+
+def emissive_triangles_from_mesh(vertices, indices, material):
+    v = np.ascontiguousarray(vertices, dtype=abi.VERTEX)
+    i = np.ascontiguousarray(indices, dtype=np.uint32)
+    m = np.ascontiguousarray(material, dtype=abi.MATERIAL)
+    out = np.zeros(max(len(i) // 3, 1), dtype=abi.EMISSIVE_TRIANGLE)
+    n = C.c_uint32()
+    check(lib().sr_emissive_triangles_from_mesh(_p(v), C.c_uint32(len(v)), _p(i), C.c_uint32(len(i)), _p(m), _p(out), C.c_uint32(len(out)), C.byref(n)))
+    return out[: n.value].copy()
+
+
+def host_bvh(v0_e1_e2):
+    """Host-only BVH build (no GPU): returns (nodes[n,16] f32, tris[n,12] f32, max_depth)."""
+    v = np.ascontiguousarray(v0_e1_e2, dtype=np.float32).reshape(-1, 9)
+    h = C.c_void_p()
+    check(lib().sr_host_bvh_build(_p(v), C.c_uint32(len(v)), C.byref(h)))
+    try:
+        np_, tp = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+        nn, nt, md = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().sr_host_bvh_get(h, C.byref(np_), C.byref(nn), C.byref(tp), C.byref(nt), C.byref(md)))
+        nodes = np.ctypeslib.as_array(np_, shape=(nn.value, 16)).copy()
+        tris = np.ctypeslib.as_array(tp, shape=(nt.value, 12)).copy() if nt.value else np.zeros((0, 12), np.float32)
+    finally:
+        lib().sr_host_bvh_destroy(h)
+    return nodes, tris, md.value
+
+
+class DeviceFrame:
+    """Frame buffers in HBM with the layouts of SrRtParams (torch tensors on one device)."""
+
+    def __init__(self, width, height, blue_noise, device="cuda:0"):
+        import torch
+        self.width, self.height = width, height
+        n = width * height
+        self.device = torch.device(device)
+        z = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype, device=self.device)
+        self.raw_color = z(n, 4, dtype=torch.float32)
+        self.depth = z(n, dtype=torch.int16)       # R16_SFLOAT bits
+        self.normal = z(n, dtype=torch.int32)      # R8G8B8A8_SNORM
+        self.diffuse = z(n, dtype=torch.int32)     # B10G11R11_UFLOAT
+        self.motion = z(n, dtype=torch.int32)      # R16G16_SFLOAT
+        self.reservoirs = [z(n, 12, dtype=torch.int32), z(n, 12, dtype=torch.int32)]      # 48 B records
+        self.reservoirs_gi = [z(n, 12, dtype=torch.int32), z(n, 12, dtype=torch.int32)]
+        bn = np.ascontiguousarray(blue_noise, dtype=np.uint8)
+        self.blue_noise_shape = bn.shape[:2]
+        self.blue_noise = torch.from_numpy(bn.copy()).to(self.device)
+
+    # host copies in the oracle's dtypes
+    def host(self):
+        out = {
+            "raw_color": self.raw_color.cpu().numpy(),
+            "depth": self.depth.cpu().numpy().view(np.uint16),
+            "normal": self.normal.cpu().numpy().view(np.uint32),
+            "diffuse": self.diffuse.cpu().numpy().view(np.uint32),
+            "motion": self.motion.cpu().numpy().view(np.uint32),
+            "reservoirs": [r.cpu().numpy().view(np.uint32).reshape(-1).view(abi.RESERVOIR) for r in self.reservoirs],
+            "reservoirs_gi": [r.cpu().numpy().view(np.uint32).reshape(-1).view(abi.RESERVOIR_GI) for r in self.reservoirs_gi],
+        }
+        return out
+
+
+class Scene:
+    """ResourceManager + acceleration structures of one GPU (sr_scene_*)."""
+
+    def __init__(self, device_index=0):
+        self._h = C.c_void_p()
+        check(lib().sr_scene_create(C.c_int(device_index), C.byref(self._h)))
+        self.device_index = device_index
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sr_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # Renderer::load_mesh (lib.rs:873-954)
+    def add_mesh(self, key, vertices, indices, material):
+        v = np.ascontiguousarray(vertices, dtype=abi.VERTEX)
+        i = np.ascontiguousarray(indices, dtype=np.uint32)
+        m = np.ascontiguousarray(material, dtype=abi.MATERIAL)
+        slot = C.c_uint32()
+        check(lib().sr_scene_add_mesh(self._h, C.c_uint64(key), _p(v), C.c_uint32(len(v)), _p(i), C.c_uint32(len(i)), _p(m), C.byref(slot)))
+        return slot.value
+
+    # frame_instance_data (resource_manager.rs:216-267) + TLAS build
+    def set_instances(self, instances):
+        keys = np.array([k for k, _ in instances], dtype=np.uint64)
+        counts = np.array([len(t) for _, t in instances], dtype=np.uint32)
+        xf = np.array([np.asarray(t, dtype=np.float32).reshape(12) for _, ts in instances for t in ts], dtype=np.float32).reshape(-1, 12)
+        if len(xf) == 0:
+            xf = np.zeros((1, 12), dtype=np.float32)
+        check(lib().sr_scene_set_instances(self._h, _p(keys), _p(counts), C.c_uint32(len(keys)), _p(np.ascontiguousarray(xf))))
+
+    def load(self, desc):
+        for m in desc.meshes:
+            self.add_mesh(m.key, m.vertices, m.indices, m.material)
+        self.set_instances(desc.instances)
+        return self
+
+    def tables(self):
+        tp, ip, ep, mp = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nt, nl, ne, nm = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().sr_scene_get_tables(self._h, C.byref(tp), C.byref(nt), C.byref(ip), C.byref(nl), C.byref(ep), C.byref(ne), C.byref(mp), C.byref(nm)))
+
+        def arr(ptr, n, dt):
+            if n == 0:
+                return np.zeros(0, dtype=dt)
+            buf = (C.c_char * (n * dt.itemsize)).from_address(ptr.value)
+            return np.frombuffer(buf, dtype=dt).copy()
+        return {"transforms": arr(tp, nt.value, abi.TRANSFORM), "indirection": arr(ip, nl.value, abi.EMISSIVE_INDIRECTION),
+                "emissive_triangles": arr(ep, ne.value, abi.EMISSIVE_TRIANGLE), "num_lights": nl.value,
+                "meshes_info": arr(mp, nm.value, abi.MESH_INFO)}
+
+    def bvh_stats(self):
+        s = abi.SrBvhStats()
+        check(lib().sr_scene_bvh_stats(self._h, C.byref(s)))
+        return s
+
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # TraceRay test hooks: torch uint8/any tensors holding abi.RAY records
+    def trace_closest(self, rays_t, n):
+        import torch
+        hits = torch.empty(n, 4, dtype=torch.float32, device=rays_t.device)
+        check(lib().sr_trace_closest(self._h, C.c_void_p(rays_t.data_ptr()), C.c_uint32(n), C.c_void_p(hits.data_ptr()), self._stream()))
+        return hits
+
+    def trace_any(self, rays_t, n):
+        import torch
+        occ = torch.empty(n, dtype=torch.int32, device=rays_t.device)
+        check(lib().sr_trace_any(self._h, C.c_void_p(rays_t.data_ptr()), C.c_uint32(n), C.c_void_p(occ.data_ptr()), self._stream()))
+        return occ
+
+    def shade_closest_hit(self, hits_t, n):
+        import torch
+        out = torch.empty(n, 8, dtype=torch.int32, device=hits_t.device)
+        check(lib().sr_shade_closest_hit(self._h, C.c_void_p(hits_t.data_ptr()), C.c_uint32(n), C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def params(self, frame, matrices, frame_count, config=None, tile=None):
+        p = abi.SrRtParams()
+        p.scene = self._h
+        p.raw_color = frame.raw_color.data_ptr()
+        p.depth_img = frame.depth.data_ptr()
+        p.normal_img = frame.normal.data_ptr()
+        p.diffuse_img = frame.diffuse.data_ptr()
+        p.motion_vec_img = frame.motion.data_ptr()
+        self._m = matrices
+        p.matrices = C.pointer(matrices)
+        p.blue_noise_tex = frame.blue_noise.data_ptr()
+        p.blue_noise_h, p.blue_noise_w = frame.blue_noise_shape
+        p.reservoirs[0], p.reservoirs[1] = frame.reservoirs[0].data_ptr(), frame.reservoirs[1].data_ptr()
+        p.reservoirs_gi[0], p.reservoirs_gi[1] = frame.reservoirs_gi[0].data_ptr(), frame.reservoirs_gi[1].data_ptr()
+        p.frame_count = frame_count
+        p.use_srgb = 0
+        p.width, p.height = frame.width, frame.height
+        if tile:
+            p.tile_y0, p.tile_h = tile
+        p.config = config or abi.SrTraceConfig.reference()
+        return p
+
+    def trace_ris(self, frame, matrices, frame_count, config=None, tile=None):
+        p = self.params(frame, matrices, frame_count, config, tile)
+        check(lib().sr_trace_ris(C.byref(p), self._stream()))
+
+    def trace_final(self, frame, matrices, frame_count, config=None, tile=None):
+        p = self.params(frame, matrices, frame_count, config, tile)
+        check(lib().sr_trace_final(C.byref(p), self._stream()))
+
+    def reset_counters(self):
+        check(lib().sr_scene_reset_counters(self._h, self._stream()))
+
+    def counters(self):
+        c = abi.SrRayCounters()
+        check(lib().sr_scene_read_counters(self._h, self._stream(), C.byref(c)))
+        return c
+
+    def set_instrumented(self, on):
+        check(lib().sr_scene_set_instrumented(self._h, C.c_int(1 if on else 0)))
+
+    def enable_timing(self, on):
+        check(lib().sr_scene_enable_timing(self._h, C.c_int(1 if on else 0)))
+
+    def read_timing(self, kind):
+        ms, n = C.c_double(), C.c_uint32()
+        check(lib().sr_scene_read_timing(self._h, C.c_int(kind), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def rays_to_device(rays_np, device="cuda:0"):
+    import torch
+    a = np.ascontiguousarray(rays_np, dtype=abi.RAY)
+    return torch.from_numpy(a.view(np.float32).reshape(-1, 8).copy()).to(device)
+
+
+def hits_from_device(hits_t):
+    return hits_t.cpu().numpy().reshape(-1).view(abi.HIT)
