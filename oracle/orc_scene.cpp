@@ -242,6 +242,11 @@ void Scene::build_bvh() {
         const WTri& t = tris[i];
         Box b = empty_box();
         grow(b, t.v0); grow(b, t.v0 + t.e1); grow(b, t.v0 + t.e2);
+        // intersect_tri accepts barycentrics up to kBaryEps outside the triangle (and rounds): the box
+        // must contain that fattened triangle, or BVH and brute force disagree at silhouette edges.
+        V3 pad = V3{fabsf(t.e1.x) + fabsf(t.e2.x), fabsf(t.e1.y) + fabsf(t.e2.y), fabsf(t.e1.z) + fabsf(t.e2.z)} * (4.0f * kBaryEps);
+        b.lo = b.lo - pad - V3{fabsf(b.lo.x), fabsf(b.lo.y), fabsf(b.lo.z)} * 2e-7f;
+        b.hi = b.hi + pad + V3{fabsf(b.hi.x), fabsf(b.hi.y), fabsf(b.hi.z)} * 2e-7f;
         tb[i] = b;
         cen[i] = (b.lo + b.hi) * 0.5f;
         order[i] = i;
@@ -302,16 +307,18 @@ void Scene::build_bvh() {
 }
 
 // Conservative slab test: never rejects a box a triangle hit with t in (t_lo, t_hi] could lie in.
-// The near bound is relaxed and the far bound inflated (Ize 2013, "Robust BVH Ray Traversal").
+// Planes are taken in the ray's own order (near plane = hi when the direction is negative), so a
+// zero direction component gives -inf/+inf for an origin strictly inside the slab and NaN for an
+// origin exactly on a face; fmaxf/fminf drop the NaN, i.e. the slab is closed. The far bound is
+// inflated (Ize 2013, "Robust BVH Ray Traversal").
 static inline float inflate(float f) { return f + fabsf(f) * 5e-7f; }
-static inline bool box_hit(const BvhNode& n, V3 o, V3 inv, float t_lo, float t_hi, float& tnear) {
-    float t0 = t_lo, t1 = t_hi;
-    float a = (n.lo.x - o.x) * inv.x, b = (n.hi.x - o.x) * inv.x;
-    t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, inflate(fmaxf(a, b)));
-    a = (n.lo.y - o.y) * inv.y; b = (n.hi.y - o.y) * inv.y;
-    t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, inflate(fmaxf(a, b)));
-    a = (n.lo.z - o.z) * inv.z; b = (n.hi.z - o.z) * inv.z;
-    t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, inflate(fmaxf(a, b)));
+struct RaySigns { bool x, y, z; };
+static inline bool box_hit(const BvhNode& n, V3 o, V3 inv, RaySigns sg, float t_lo, float t_hi, float& tnear) {
+    float nx = ((sg.x ? n.hi.x : n.lo.x) - o.x) * inv.x, fx = ((sg.x ? n.lo.x : n.hi.x) - o.x) * inv.x;
+    float ny = ((sg.y ? n.hi.y : n.lo.y) - o.y) * inv.y, fy = ((sg.y ? n.lo.y : n.hi.y) - o.y) * inv.y;
+    float nz = ((sg.z ? n.hi.z : n.lo.z) - o.z) * inv.z, fz = ((sg.z ? n.lo.z : n.hi.z) - o.z) * inv.z;
+    float t0 = fmaxf(fmaxf(nx, ny), fmaxf(nz, t_lo));
+    float t1 = fminf(inflate(fminf(fminf(fx, fy), fz)), t_hi);
     tnear = t0;
     return t0 <= t1;
 }
@@ -319,15 +326,18 @@ static inline bool box_hit(const BvhNode& n, V3 o, V3 inv, float t_lo, float t_h
 Hit Scene::closest_bvh(V3 o, V3 d, float tmin, float tmax, Counters* c) const {
     Hit best{-1.0f, 0.0f, 0.0f, 0xFFFFFFFFu};
     if (nodes.empty()) return best;
-    V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-    float t_lo = tmin - fabsf(tmin) * 1e-5f;
+    const V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    const RaySigns sg{std::signbit(inv.x), std::signbit(inv.y), std::signbit(inv.z)};
+    // Near bound of the box test: one |tmin| BELOW tmin. Close to the origin the triangle test's t carries
+    // an absolute error far above 1e-5*tmin (cancellation in o - v0), so a relative slack is not enough.
+    const float t_lo = fminf(tmin, 0.0f) - fabsf(tmin);
     float best_t = tmax;
     float cull = tmax + fabsf(tmax) * 1e-5f;  // relaxed on both ends; only intersect_tri applies the exact bounds
     uint32_t stack[96]; int sp = 0;
     stack[sp++] = 0;
     float tn;
     if (c) c->boxes++;
-    if (!box_hit(nodes[0], o, inv, t_lo, cull, tn)) return best;
+    if (!box_hit(nodes[0], o, inv, sg, t_lo, cull, tn)) return best;
     while (sp > 0) {
         const BvhNode& n = nodes[stack[--sp]];
         if (n.count > 0) {
@@ -346,8 +356,8 @@ Hit Scene::closest_bvh(V3 o, V3 d, float tmin, float tmax, Counters* c) const {
         }
         float tl, tr;
         if (c) c->boxes += 2;
-        bool hl = box_hit(nodes[n.left], o, inv, t_lo, cull, tl);
-        bool hr = box_hit(nodes[n.right], o, inv, t_lo, cull, tr);
+        bool hl = box_hit(nodes[n.left], o, inv, sg, t_lo, cull, tl);
+        bool hr = box_hit(nodes[n.right], o, inv, sg, t_lo, cull, tr);
         if (hl && hr) {
             if (tl <= tr) { stack[sp++] = n.right; stack[sp++] = n.left; }
             else { stack[sp++] = n.left; stack[sp++] = n.right; }
@@ -359,14 +369,17 @@ Hit Scene::closest_bvh(V3 o, V3 d, float tmin, float tmax, Counters* c) const {
 
 bool Scene::any_bvh(V3 o, V3 d, float tmin, float tmax, Counters* c) const {
     if (nodes.empty()) return false;
-    V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-    float t_lo = tmin - fabsf(tmin) * 1e-5f;
+    const V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    const RaySigns sg{std::signbit(inv.x), std::signbit(inv.y), std::signbit(inv.z)};
+    // Near bound of the box test: one |tmin| BELOW tmin. Close to the origin the triangle test's t carries
+    // an absolute error far above 1e-5*tmin (cancellation in o - v0), so a relative slack is not enough.
+    const float t_lo = fminf(tmin, 0.0f) - fabsf(tmin);
     const float t_hi = tmax + fabsf(tmax) * 1e-5f;
     uint32_t stack[96]; int sp = 0;
     stack[sp++] = 0;
     float tn;
     if (c) c->boxes++;
-    if (!box_hit(nodes[0], o, inv, t_lo, t_hi, tn)) return false;
+    if (!box_hit(nodes[0], o, inv, sg, t_lo, t_hi, tn)) return false;
     while (sp > 0) {
         const BvhNode& n = nodes[stack[--sp]];
         if (n.count > 0) {
@@ -378,8 +391,8 @@ bool Scene::any_bvh(V3 o, V3 d, float tmin, float tmax, Counters* c) const {
             continue;
         }
         if (c) c->boxes += 2;
-        if (box_hit(nodes[n.left], o, inv, t_lo, t_hi, tn)) stack[sp++] = n.left;
-        if (box_hit(nodes[n.right], o, inv, t_lo, t_hi, tn)) stack[sp++] = n.right;
+        if (box_hit(nodes[n.left], o, inv, sg, t_lo, t_hi, tn)) stack[sp++] = n.left;
+        if (box_hit(nodes[n.right], o, inv, sg, t_lo, t_hi, tn)) stack[sp++] = n.right;
     }
     return false;
 }

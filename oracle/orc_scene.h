@@ -92,6 +92,9 @@ void material_new(const float base_color[4], float metallic, float roughness, co
 void inverse3x3(const SrTransform& t, float out[9]);
 
 // The canonical Möller–Trumbore test: explicit fmaf in dot/cross, exclusive (tmin,tmax).
+// The barycentric bounds are widened by kBaryEps so that a ray through a shared edge hits at least one
+// of the two triangles (plain MT leaves cracks there; the Vulkan triangle test is watertight).
+constexpr float kBaryEps = 1e-6f;
 static inline float dot_fma(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 static inline V3 cross_fma(V3 a, V3 b) {
     return V3{fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
@@ -105,7 +108,7 @@ static inline bool intersect_tri(V3 o, V3 d, const WTri& tr, float tmin, float t
     V3 qvec = cross_fma(tvec, tr.e1);
     v = dot_fma(d, qvec) * inv;
     t = dot_fma(tr.e2, qvec) * inv;
-    return (u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f) && (t > tmin) && (t < tmax);
+    return (u >= -kBaryEps) && (v >= -kBaryEps) && (u + v <= 1.0f + kBaryEps) && (t > tmin) && (t < tmax);
 }
 
 struct PassParams {

@@ -56,3 +56,5 @@ if __name__ == "__main__":
         compare(scenes.torus_knot(), 480, 270, 2)
     elif which == "height":
         compare(scenes.heightfield(708), 480, 270, 2)
+    elif which == "heightfull":
+        compare(scenes.heightfield(708), 1920, 1080, 5)

@@ -241,6 +241,12 @@ void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult&
         float p1[3], p2[3];
         for (int a = 0; a < 3; a++) { p1[a] = t.v0[a] + t.e1[a]; p2[a] = t.v0[a] + t.e2[a]; }
         Aabb bb; bb.reset(); bb.add(t.v0); bb.add(p1); bb.add(p2);
+        // The triangle test accepts barycentrics up to kBaryEps (1e-6) outside the triangle: bound that
+        // fattened triangle, with margin for the test's own rounding (traverse.h intersect_tri).
+        for (int a = 0; a < 3; a++) {
+            const float pad = 4e-6f * (std::fabs(t.e1[a]) + std::fabs(t.e2[a]));
+            bb.lo[a] -= pad; bb.hi[a] += pad;
+        }
         b.bounds[i] = bb;
         for (int a = 0; a < 3; a++) b.centroid[a][i] = 0.5f * bb.lo[a] + 0.5f * bb.hi[a];
         b.order[i] = i;

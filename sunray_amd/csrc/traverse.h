@@ -51,7 +51,10 @@ struct TravHit {
 struct TravStats { uint32_t boxes, tris; };
 
 // The canonical Möller–Trumbore test. fmaf is spelled out so that the oracle's
-// scalar code and this kernel round identically; bounds are exclusive on both sides.
+// scalar code and this kernel round identically; (tmin, tmax) is exclusive on both sides. The
+// barycentric bounds are widened by kBaryEps so a ray through a shared edge hits at least one of the
+// two triangles (plain MT leaves cracks there; the Vulkan triangle test is watertight).
+constexpr float kBaryEps = 1e-6f;
 SRD float dot_fma(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 SRD f3 cross_fma(f3 a, f3 b) {
     return mk3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
@@ -65,20 +68,34 @@ SRD bool intersect_tri(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax, 
     f3 qvec = cross_fma(tvec, e1);
     v = dot_fma(d, qvec) * inv;
     t = dot_fma(e2, qvec) * inv;
-    return (u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f) && (t > tmin) && (t < tmax);
+    return (u >= -kBaryEps) && (v >= -kBaryEps) && (u + v <= 1.0f + kBaryEps) && (t > tmin) && (t < tmax);
 }
 
 // Conservative slab test: a box is only rejected if no triangle hit with t in (t_lo, t_hi] can lie
-// inside it — the near side is compared against a relaxed bound and the far side is inflated
-// (Ize 2013). min/max are the IEEE minNum/maxNum forms, so a 0*inf NaN drops out of the slab.
-SRD bool slab(float lox, float hix, float loy, float hiy, float loz, float hiz, f3 o, f3 inv, float t_lo, float t_hi, float& tnear) {
-    float ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
-    float ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
-    float az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
-    float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), t_lo));
-    float far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+// inside it. Planes are taken in the ray's own order (near plane = hi for a negative direction), so
+// a zero direction component yields -inf/+inf inside the slab and NaN exactly on a face; v_max/v_min
+// (IEEE maxNum/minNum) drop the NaN, i.e. slabs are closed. The far side is inflated (Ize 2013).
+struct RaySetup {
+    f3 o, inv;
+    bool sx, sy, sz;
+};
+SRD RaySetup ray_setup(f3 o, f3 d) {
+    RaySetup r;
+    r.o = o;
+    r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.sx = (__float_as_uint(r.inv.x) >> 31) != 0u;
+    r.sy = (__float_as_uint(r.inv.y) >> 31) != 0u;
+    r.sz = (__float_as_uint(r.inv.z) >> 31) != 0u;
+    return r;
+}
+SRD bool slab(float lox, float hix, float loy, float hiy, float loz, float hiz, const RaySetup& r, float t_lo, float t_hi, float& tnear) {
+    const float nx = ((r.sx ? hix : lox) - r.o.x) * r.inv.x, fx = ((r.sx ? lox : hix) - r.o.x) * r.inv.x;
+    const float ny = ((r.sy ? hiy : loy) - r.o.y) * r.inv.y, fy = ((r.sy ? loy : hiy) - r.o.y) * r.inv.y;
+    const float nz = ((r.sz ? hiz : loz) - r.o.z) * r.inv.z, fz = ((r.sz ? loz : hiz) - r.o.z) * r.inv.z;
+    const float t0 = fmaxf(fmaxf(nx, ny), fmaxf(nz, t_lo));
+    float far = fminf(fminf(fx, fy), fz);
     far = fmaf(fabsf(far), 5e-7f, far);
-    float t1 = fminf(far, t_hi);
+    const float t1 = fminf(far, t_hi);
     tnear = t0;
     return t0 <= t1;
 }
@@ -88,8 +105,10 @@ template <bool ANY, bool STATS>
 SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHit& hit, int* stack, int stride, TravStats& st) {
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ tris = sc.tris;
-    f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const float t_lo = tmin - fabsf(tmin) * 1e-5f;
+    const RaySetup rs = ray_setup(o, d);
+    // Near bound of the box test: one |tmin| BELOW tmin. Close to the origin the triangle test's t carries
+    // an absolute error far above 1e-5*tmin (cancellation in o - v0), so a relative slack is not enough.
+    const float t_lo = fminf(tmin, 0.0f) - fabsf(tmin);
     // Box culling bounds are relaxed on both ends; only the triangle test applies the exact (tmin, tmax).
     float cull = fmaf(fabsf(tmax), 1e-5f, tmax);
     float best_t = tmax;
@@ -103,8 +122,8 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
             const float4 n2 = nodes[node * 4 + 2];
             const float4 n3 = nodes[node * 4 + 3];
             float tn0, tn1;
-            const bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n2.x, n2.y, o, inv, t_lo, cull, tn0);
-            const bool h1 = slab(n1.x, n1.y, n1.z, n1.w, n2.z, n2.w, o, inv, t_lo, cull, tn1);
+            const bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n2.x, n2.y, rs, t_lo, cull, tn0);
+            const bool h1 = slab(n1.x, n1.y, n1.z, n1.w, n2.z, n2.w, rs, t_lo, cull, tn1);
             if (STATS) st.boxes += 2;
             int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
             if (h0 && h1) {

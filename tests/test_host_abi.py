@@ -1,0 +1,171 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/sunray_hip.h
+declares, its host-side data preparation (H1..H6) equals the oracle's, the BVH builder produces a
+valid tree, and device entry points fail loudly without a GPU. No compute calls need a GPU here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from sunray_amd import _lib, abi, runtime as rt, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "sunray_hip.h")).read()
+    declared = set(re.findall(r"\b(sr_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.sr_version() == 1
+
+
+def test_abi_struct_sizes_match_header():
+    assert C.sizeof(abi.SrRtParams) == 160 and C.sizeof(abi.SrTraceConfig) == 32 and C.sizeof(abi.SrMatrices) == 256
+    cfg = abi.SrTraceConfig()
+    _lib.lib().sr_trace_config_default(C.byref(cfg))
+    ref = abi.SrTraceConfig.reference()
+    assert bytes(cfg) == bytes(ref)
+    assert (cfg.max_bounces, cfg.shadow_bounces, cfg.ris_candidates, cfg.virtual_bounces, cfg.enable_restir) == (10, 5, 16, 20, 1)
+
+
+def test_camera_matrices_match_oracle_and_closed_form(oracle):
+    for pos, tgt, fov, w, h in [((0, 0, 1), (0, 0, 0), 45.0, 256, 256), ((13, 30, 25), (0, 13, 0), 45.0, 1600, 1200),
+                                ((0.0, 11.0, 21.0), (0.0, 0.5, 0.0), 60.0, 1920, 1080)]:
+        a = rt.camera_matrices(pos, tgt, fov, w, h)
+        b = oracle.camera_matrices(pos, tgt, fov, w, h)
+        assert bytes(a) == bytes(b)
+        vi = np.array(list(a.view_inverse)).reshape(4, 4)
+        pi = np.array(list(a.proj_inverse)).reshape(4, 4)
+        vp = np.array(list(a.view_proj)).reshape(4, 4)
+        assert not np.array(list(a.prev_view_proj)).any()          # zero on the first frame (lib.rs:410)
+        assert np.allclose(vi[:3, 3], pos, atol=1e-5)              # origin = V^-1 (0,0,0,1)
+        # SURVEY §8a H1 closed form: P^-1 (dx,dy,1,1).xyz = (dx*aspect*tan, -dy*tan, -1)
+        t = np.tan(np.radians(fov) / 2)
+        v = pi @ np.array([0.3, -0.7, 1, 1])
+        assert np.allclose(v[:3], [0.3 * (w / h) * t, 0.7 * t, -1], atol=1e-5) and abs(v[3] - 0.01) < 1e-4
+        # view_proj * (target) lands on the optical axis
+        c = vp @ np.array(list(tgt) + [1.0])
+        assert abs(c[0] / c[3]) < 1e-4 and abs(c[1] / c[3]) < 1e-4
+    a2 = rt.camera_matrices((0, 0, 1), (0, 0, 0), 45.0, 256, 256, prev_view_proj=list(a.view_proj))
+    assert list(a2.prev_view_proj) == list(a.view_proj)
+    with pytest.raises(_lib.SunrayError):
+        rt.camera_matrices((0, 0, 1), (0, 0, 0), 45.0, 0, 256)
+
+
+def test_material_and_emissive_derivation_match_oracle(oracle):
+    m = rt.material_new((0.1, 0.2, 0.3, 1.0), 0.4, 0.6, (1.0, 0.5, 0.25), 3.0, 0.7, 1.45)
+    mo = np.zeros((), dtype=abi.MATERIAL)
+    oracle.lib().orc_material_new((C.c_float * 4)(0.1, 0.2, 0.3, 1.0), C.c_float(0.4), C.c_float(0.6), (C.c_float * 3)(1.0, 0.5, 0.25),
+                                  C.c_float(3.0), C.c_float(0.7), C.c_float(1.45), mo.ctypes.data_as(C.c_void_p))
+    assert m.tobytes() == mo.tobytes() == abi.material((0.1, 0.2, 0.3, 1.0), 0.4, 0.6, (1.0, 0.5, 0.25), 3.0, 0.7, 1.45).tobytes()
+    assert m["alpha_mode"] == 0 and m["alpha_cutoff"] == 0 and m["normal_image"] == abi.NULL_TEXTURE  # material.rs:74-75
+    v, i = scenes.quad((-0.3, 1.99, -0.3), (0.3, 1.99, -0.3), (0.3, 1.99, 0.3), (-0.3, 1.99, 0.3), (0, -1, 0))
+    et = rt.emissive_triangles_from_mesh(v, i, m)
+    assert len(et) == 2 and np.allclose(et[0]["emission"], [3.0, 1.5, 0.75, 0.0])   # factor * strength (lib.rs:901-906)
+    assert np.allclose(et[1]["v2"], [-0.3, 1.99, 0.3, 0.0])
+    # not emissive when every component of factor*strength is <= 0 (lib.rs:907)
+    assert len(rt.emissive_triangles_from_mesh(v, i, abi.material(emissive_factor=(1, 1, 1), emissive_strength=0.0))) == 0
+
+
+def _world_tris(desc):
+    out = []
+    meshes = {m.key: m for m in desc.meshes}
+    for key, xs in desc.instances:
+        m = meshes[key]
+        P = m.vertices["position"].astype(np.float32)
+        for x in xs:
+            M = np.asarray(x, dtype=np.float32).reshape(3, 4)
+            W = (P @ M[:, :3].T + M[:, 3]).astype(np.float32)
+            t = W[m.indices.reshape(-1, 3)]
+            out.append(np.concatenate([t[:, 0], t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]], axis=1))
+    return np.concatenate(out).astype(np.float32)
+
+
+def _check_bvh(nodes, tris, max_depth):
+    n = len(tris)
+    seen = np.zeros(n, dtype=int)
+    depth_seen = [0]
+
+    def rec(node, depth):
+        depth_seen[0] = max(depth_seen[0], depth)
+        nd = nodes[node]
+        ch = nd[12:14].view(np.int32)
+        boxes = [(nd[[0, 2, 8]], nd[[1, 3, 9]]), (nd[[4, 6, 10]], nd[[5, 7, 11]])]
+        lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
+        for c in range(2):
+            lo, hi = boxes[c]
+            if ch[c] >= 0:
+                assert ch[c] > node  # depth-first order: children follow their parent
+                l2, h2 = rec(int(ch[c]), depth + 1)
+            else:
+                v = (~int(ch[c])) & 0xFFFFFFFF
+                first, cnt = v >> 3, v & 7
+                assert cnt <= 4
+                if cnt == 0:
+                    continue
+                tt = tris[first:first + cnt]
+                seen[first:first + cnt] += 1
+                p0 = tt[:, 0:3]
+                allp = np.concatenate([p0, p0 + tt[:, 3:6], p0 + tt[:, 6:9]])
+                l2, h2 = allp.min(0), allp.max(0)
+            assert (lo < l2).all() and (hi > h2).all()  # strictly: boxes are padded by one ulp
+            lo_all, hi_all = np.minimum(lo_all, l2), np.maximum(hi_all, h2)
+        return lo_all, hi_all
+
+    rec(0, 1)
+    assert (seen == 1).all()
+    assert sorted(tris[:, 11].view(np.uint32)) == list(range(n))
+    assert depth_seen[0] == max_depth <= 32  # never deeper than the kernels' LDS stack (traverse.h)
+
+
+@pytest.mark.parametrize("scene_fn", [scenes.cornell_box, scenes.cornell_glass_mirror, lambda: scenes.heightfield(n=64, n_lights=3)])
+def test_host_bvh_is_a_valid_tree(scene_fn):
+    w = _world_tris(scene_fn())
+    nodes, tris, md = rt.host_bvh(w)
+    _check_bvh(nodes, tris, md)
+
+
+def test_host_bvh_small_and_degenerate_inputs():
+    w = _world_tris(scenes.cornell_box())
+    for k in (0, 1, 3, 4, 5, 9):
+        nodes, tris, md = rt.host_bvh(w[:k])
+        assert len(tris) == k and len(nodes) >= 1  # the root is always an inner node
+        _check_bvh(nodes, tris, md)
+    # 5000 identical triangles: SAH cannot split, the median fallback must keep depth bounded
+    same = np.tile(w[:1], (5000, 1))
+    nodes, tris, md = rt.host_bvh(same)
+    _check_bvh(nodes, tris, md)
+    # a long line of tiny triangles: depth guard
+    line = np.tile(w[:1], (3000, 1))
+    line[:, 0] += np.arange(3000, dtype=np.float32) ** 2
+    nodes, tris, md = rt.host_bvh(line)
+    _check_bvh(nodes, tris, md)
+
+
+def test_device_entry_points_fail_loudly_without_gpu():
+    if has_gpu():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.SunrayError) as e:
+        rt.Scene(0)
+    assert e.value.code == -2 and "hip" in e.value.description.lower()
+    p = abi.SrRtParams()
+    L = _lib.lib()
+    assert L.sr_trace_ris(C.byref(p), None) == -1 and b"scene is null" in L.sr_last_error()
+    assert L.sr_trace_final(None, None) == -1
+    assert L.sr_trace_closest(None, None, 0, None, None) == -1
+
+
+def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(ImportError):
+        _lib.lib()
