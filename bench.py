@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X ray-tracing hot path.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json `metric`: "Mray/s + ms/frame at 1920x1080 1spp, 1M-tri scene"): one step =
+one frame = the two ray-tracing passes of the reference (raytracing_ris + raytracing_final,
+src/lib.rs:1549-1574) with the reference's constants (1 sample per pixel, 10 bounces, 16 RIS
+candidates) at 1920x1080 on the 999 714-triangle procedural heightfield (SURVEY.md §8d config 3
+scene; no 1M-triangle asset exists offline). Scene, BVH, camera matrices and every frame buffer are
+resident in HBM before the timed region. Rays are counted by the kernels (closest-hit + any-hit
+queries actually issued). With N GPUs the frame's rows are split into N strips (strong scaling of one
+frame; sunray_amd/distributed.py) and the radiance strips are all-gathered over RCCL every step.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
+KIND_RIS, KIND_FINAL = 0, 1
+
+
+def algorithmic_bytes(c, n_pixels, which):
+    """B_ray = 32*N_boxes + 48*N_tris + 32 (ray) + 16 (hit) per query, +460 B per
+    closest-hit surface fetch (128 MeshInfo + 12 indices + 288 vertices + 32 payload), plus the
+    per-pixel frame-buffer traffic of the pass (reference formats)."""
+    rays = c.closest_queries + c.any_queries
+    b = 32 * c.boxes_tested + 48 * c.tris_tested + 48 * rays + 460 * c.closest_queries
+    if which == KIND_RIS:
+        b += n_pixels * (14 + 96)            # G-buffer 2+4+4+4 B written + DI and GI reservoirs written
+    else:
+        b += n_pixels * (16 + 9 * 48 + 9 * 6)  # radiance written + up to 9 reservoir gathers + normal/depth texels
+    return b
+
+
+def cpu_baseline(desc, W, H, blue_noise, budget_s=12.0, max_frames=8):
+    """The oracle (our CPU restatement: the reference has no CPU path) timed on this host's cores on
+    the same scene / extent / constants; whole frames until ~budget_s of work."""
+    from oracle import binding as ob
+    threads = os.cpu_count() or 1
+    s = ob.OracleScene().load(desc)
+    fr = ob.HostFrame(W, H, blue_noise)
+    prev, rays, t_total, frames = None, 0, 0.0, 0
+    while frames < max_frames and (t_total < budget_s or frames < 2):
+        m = ob.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, prev)
+        prev = list(m.view_proj)
+        s.reset_counters()
+        t0 = time.perf_counter()
+        s.trace_ris(fr, m, frames)
+        s.trace_final(fr, m, frames)
+        t_total += time.perf_counter() - t0
+        c = s.counters()
+        rays += c.closest_queries + c.any_queries
+        frames += 1
+    return {"value": rays / t_total / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
+            "sample": "%d full frames at %dx%d of the same scene and constants, OpenMP over scanlines, %.1f s"
+                      % (frames, W, H, t_total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--grid", type=int, default=708, help="heightfield grid: 2*(grid-1)^2 triangles")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sunray_amd import abi, distributed as sd, runtime as rt, scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch --gpus %d through torch.distributed.run (one process per GPU)" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    W, H = args.width, args.height
+    desc = scenes.heightfield(args.grid)
+    blue_noise = scenes.white_noise_rgba8()
+    scene = rt.Scene(local_rank).load(desc)
+    st = scene.bvh_stats()
+    frame = rt.DeviceFrame(W, H, blue_noise, device=device)
+    cfg = abi.SrTraceConfig.reference()
+    per = (H + world - 1) // world
+    gathered = torch.empty(world * per * W, 4, dtype=torch.float32, device=device)
+    scratch = torch.zeros(per * W, 4, dtype=torch.float32, device=device)
+
+    state = {"prev": None, "frame": 0}
+
+    def step():
+        m = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, state["prev"])
+        state["prev"] = list(m.view_proj)
+        sd.render_strip(scene, frame, m, state["frame"], cfg, world, rank, abi.TRACE_FLAG_UNCOUNTED)
+        if world > 1:
+            sd.gather_strips(frame.raw_color, W, H, world, rank, out=gathered, scratch=scratch)
+        state["frame"] += 1
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+
+    # instrumented replay of ONE frame (untimed): boxes / triangles tested per launch of each pass
+    scene.set_instrumented(True)
+    per_kind = {}
+    m_i = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, state["prev"])
+    y0, h = sd.strip_rows(H, world, rank)
+    for kind, fn in ((KIND_RIS, scene.trace_ris), (KIND_FINAL, scene.trace_final)):
+        scene.reset_counters()
+        fn(frame, m_i, state["frame"], cfg, tile=(y0, h))
+        per_kind[kind] = scene.counters()
+    state["prev"] = list(m_i.view_proj)
+    state["frame"] += 1
+    scene.set_instrumented(False)
+    fence()
+
+    scene.reset_counters()
+    scene.enable_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    scene.enable_timing(False)
+    c = scene.counters()
+    ris_ms, ris_n = scene.read_timing(KIND_RIS)
+    fin_ms, fin_n = scene.read_timing(KIND_FINAL)
+
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    rays = torch.tensor([float(c.closest_queries + c.any_queries), float(c.closest_queries), float(c.any_queries)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    elapsed = float(t_el.item())
+    total_rays, total_closest, total_any = [float(x) for x in rays.tolist()]
+
+    if rank == 0:
+        # dominant kernel of this rank: the pass with the larger summed device time
+        dom = KIND_FINAL if fin_ms >= ris_ms else KIND_RIS
+        dom_ms, dom_n = (fin_ms, fin_n) if dom == KIND_FINAL else (ris_ms, ris_n)
+        dom_name = "final_kernel (raytracing_final)" if dom == KIND_FINAL else "ris_kernel (raytracing_ris)"
+        # with N > 1 the RIS pass is 1 strip launch + up to 2 halo launches per step: price it per step
+        avg_ms = dom_ms / max(dom_n, 1) if (dom == KIND_FINAL or world == 1) else dom_ms / args.steps
+        bytes_per_launch = algorithmic_bytes(per_kind[dom], W * h, dom)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        ck = per_kind[dom]
+        nq = max(ck.closest_queries + ck.any_queries, 1)
+        out = {
+            "metric": "Mray/s (closest-hit + any-hit queries issued per second), 1920x1080, 1 spp, 1M-triangle scene",
+            "value": total_rays / elapsed / 1e6,
+            "unit": "Mray/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "procedural heightfield %d triangles (%d BVH nodes), %dx%d, 1 spp, full reference frame per step: "
+                            "raytracing_ris + raytracing_final, 10 bounces, 16 RIS candidates, ReSTIR DI+GI on"
+                            % (st.n_triangles, st.n_nodes, W, H),
+                "rays_per_frame": total_rays / args.steps,
+                "closest_per_frame": total_closest / args.steps,
+                "any_per_frame": total_any / args.steps,
+                "parallelism": "rows split into %d strips, RIS halo %d rows recomputed, radiance all-gathered over RCCL" % (world, sd.SPATIAL_HALO) if world > 1 else "single GPU",
+                "bvh_build_ms_host": st.build_ms,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom_name,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_ms": avg_ms,
+                "launches_timed": dom_n,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "boxes_per_ray": ck.boxes_tested / nq,
+                "tris_per_ray": ck.tris_tested / nq,
+                "other_pass_avg_ms": (ris_ms / max(ris_n, 1)) if dom == KIND_FINAL else (fin_ms / max(fin_n, 1)),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(desc, W, H, blue_noise)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

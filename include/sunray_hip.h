@@ -178,8 +178,14 @@ typedef struct SrTraceConfig {
                                  starts with restir_evaluated = true, so every rough bounce takes the
                                  plain NEE branch (ray_gen_final.slang:328-382); the RIS pass is not
                                  needed (BASELINE.json configs 2, 3, 5).                           */
-    uint32_t _reserved[3];
+    uint32_t flags;           /* SR_TRACE_FLAG_* */
+    uint32_t _reserved[2];
 } SrTraceConfig;
+
+/* Do not add this launch's rays to the scene's ray counters: used for the halo rows a GPU re-traces
+ * for its neighbours' spatial reuse in tile-parallel rendering, so that counted rays are
+ * exactly the rays of the equivalent single-GPU frame. */
+#define SR_TRACE_FLAG_UNCOUNTED 1u
 
 typedef struct SrScene SrScene; /* opaque: mesh tables + instance tables + BVH ("TLAS") on one GPU */
 
@@ -357,6 +363,9 @@ int sr_scene_read_counters(SrScene* scene, void* stream, SrRayCounters* out);
 /* Instrumented kernels (count child boxes / triangle records tested, SURVEY §8d B_ray accounting).
  * Off by default: the counting costs registers and time. */
 int sr_scene_set_instrumented(SrScene* scene, int on);
+/* Instrumented build only: the ray with the most box tests (> 20000) since the last counter reset.
+ * out10[0] = box tests (0 = none), out10[1] = 1 for an any-hit query, out10[2..9] = the SrRay bits. */
+int sr_scene_debug_worst_ray(SrScene* scene, uint32_t* out10);
 
 /* Per-launch device timing: when enabled every sr_trace_* launch is bracketed by a HIP event pair
  * recorded on the launch's own stream. sr_scene_read_timing waits for the recorded launches of one

@@ -311,7 +311,7 @@ void Scene::build_bvh() {
 // zero direction component gives -inf/+inf for an origin strictly inside the slab and NaN for an
 // origin exactly on a face; fmaxf/fminf drop the NaN, i.e. the slab is closed. The far bound is
 // inflated (Ize 2013, "Robust BVH Ray Traversal").
-static inline float inflate(float f) { return f + fabsf(f) * 5e-7f; }
+static inline float inflate(float f) { return f * (1.0f + copysignf(5e-7f, f)); }  // away from zero; keeps +-inf
 struct RaySigns { bool x, y, z; };
 static inline bool box_hit(const BvhNode& n, V3 o, V3 inv, RaySigns sg, float t_lo, float t_hi, float& tnear) {
     float nx = ((sg.x ? n.hi.x : n.lo.x) - o.x) * inv.x, fx = ((sg.x ? n.lo.x : n.hi.x) - o.x) * inv.x;

@@ -8,6 +8,7 @@ import ctypes as C
 import numpy as np
 
 NULL_TEXTURE = 0xFFFFFFFF
+TRACE_FLAG_UNCOUNTED = 1
 
 # T1 VertexAttributes (rt_types.slang:24-36) — 96 B
 VERTEX = np.dtype([
@@ -51,12 +52,13 @@ class SrMatrices(C.Structure):  # T6, 256 B; every float[16] = 4 rows
 
 class SrTraceConfig(C.Structure):
     _fields_ = [("max_bounces", C.c_uint32), ("shadow_bounces", C.c_uint32), ("ris_candidates", C.c_uint32),
-                ("virtual_bounces", C.c_uint32), ("enable_restir", C.c_uint32), ("_reserved", C.c_uint32 * 3)]
+                ("virtual_bounces", C.c_uint32), ("enable_restir", C.c_uint32), ("flags", C.c_uint32),
+                ("_reserved", C.c_uint32 * 2)]
 
     @staticmethod
     def reference():
         """The reference's compile-time constants (ray_gen_final.slang:40-42, ray_gen_ris.slang:69,187)."""
-        return SrTraceConfig(10, 5, 16, 20, 1, (C.c_uint32 * 3)(0, 0, 0))
+        return SrTraceConfig(10, 5, 16, 20, 1, 0, (C.c_uint32 * 2)(0, 0))
 
 
 class SrRtParams(C.Structure):  # T9

@@ -31,9 +31,9 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    os.makedirs(os.path.join(HERE, "_obj"), exist_ok=True)
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src + ".o")
+        obj = os.path.join(HERE, "_obj", src + ".o")
         cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -152,7 +152,7 @@ int sr_scene_create(int device, SrScene** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
     // counters (4 x u64) + queue head, in one small allocation of their own
-    const unsigned long long zeros[8] = {0};
+    const unsigned long long zeros[32] = {0};
     int rc = s->d_misc.upload(zeros, sizeof(zeros));
     if (rc != SR_OK) { delete s; return rc; }
     *out = s;
@@ -394,6 +394,7 @@ int sr_scene_reset_counters(SrScene* s, void* stream) {
     int rc = bind_device(s);
     if (rc != SR_OK) return rc;
     HIP_TRY(hipMemsetAsync(s->d_misc.p, 0, 32, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync((char*)s->d_misc.p + 64, 0, 64, (hipStream_t)stream));
     return SR_OK;
 }
 
@@ -408,6 +409,20 @@ int sr_scene_read_counters(SrScene* s, void* stream, SrRayCounters* out) {
     return SR_OK;
 }
 
+// Diagnostics of the instrumented build: the ray with the most box tests (> 20000) since the last
+// counter reset: out[0] = box tests, out[1] = 1 for an any-hit query, out[2..9] = the SrRay as float bits.
+int sr_scene_debug_worst_ray(SrScene* s, uint32_t* out10) {
+    if (!s || !out10) return fail(SR_ERR_INVALID_ARG, "sr_scene_debug_worst_ray: null argument");
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    uint32_t v[16];
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(v, (char*)s->d_misc.p + 64, sizeof(v), hipMemcpyDeviceToHost));
+    out10[0] = v[0]; out10[1] = v[1];
+    for (int i = 0; i < 8; i++) out10[2 + i] = v[8 + i];
+    return SR_OK;
+}
+
 int sr_scene_set_instrumented(SrScene* s, int on) {
     if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_set_instrumented: scene is null");
     s->instrumented = on ? 1 : 0;
@@ -416,8 +431,8 @@ int sr_scene_set_instrumented(SrScene* s, int on) {
 
 int sr_scene_enable_timing(SrScene* s, int enable) {
     if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_enable_timing: scene is null");
+    if (enable && !s->timing) for (int k = 0; k < kNumKinds; k++) s->events_used[k] = 0;
     s->timing = enable ? 1 : 0;
-    for (int k = 0; k < kNumKinds; k++) s->events_used[k] = 0;
     return SR_OK;
 }
 

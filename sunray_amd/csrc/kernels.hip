@@ -430,9 +430,11 @@ __global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
             store48(reservoir_gi_cur + pix, gi);
         }
     }
-    flush_counter(sc.counters + 0, cx.n_closest);
-    flush_counter(sc.counters + 1, cx.n_any);
-    if (STATS) { flush_counter(sc.counters + 2, cx.st.boxes); flush_counter(sc.counters + 3, cx.st.tris); }
+    if (!(a.cfg.flags & SR_TRACE_FLAG_UNCOUNTED)) {
+        flush_counter(sc.counters + 0, cx.n_closest);
+        flush_counter(sc.counters + 1, cx.n_any);
+        if (STATS) { flush_counter(sc.counters + 2, cx.st.boxes); flush_counter(sc.counters + 3, cx.st.tris); }
+    }
 }
 
 template <bool STATS>
@@ -696,9 +698,11 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
         o.x = color.x; o.y = color.y; o.z = color.z; o.w = 1.0f;
         reinterpret_cast<float4*>(a.raw_color)[pix] = o;
     }
-    flush_counter(sc.counters + 0, cx.n_closest);
-    flush_counter(sc.counters + 1, cx.n_any);
-    if (STATS) { flush_counter(sc.counters + 2, cx.st.boxes); flush_counter(sc.counters + 3, cx.st.tris); }
+    if (!(a.cfg.flags & SR_TRACE_FLAG_UNCOUNTED)) {
+        flush_counter(sc.counters + 0, cx.n_closest);
+        flush_counter(sc.counters + 1, cx.n_any);
+        if (STATS) { flush_counter(sc.counters + 2, cx.st.boxes); flush_counter(sc.counters + 3, cx.st.tris); }
+    }
 }
 
 }  // namespace srd

@@ -94,7 +94,7 @@ SRD bool slab(float lox, float hix, float loy, float hiy, float loz, float hiz, 
     const float nz = ((r.sz ? hiz : loz) - r.o.z) * r.inv.z, fz = ((r.sz ? loz : hiz) - r.o.z) * r.inv.z;
     const float t0 = fmaxf(fmaxf(nx, ny), fmaxf(nz, t_lo));
     float far = fminf(fminf(fx, fy), fz);
-    far = fmaf(fabsf(far), 5e-7f, far);
+    far = far * (1.0f + copysignf(5e-7f, far));  // away from zero; keeps +-inf (an fma form turns -inf into NaN)
     const float t1 = fminf(far, t_hi);
     tnear = t0;
     return t0 <= t1;
@@ -106,6 +106,7 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ tris = sc.tris;
     const RaySetup rs = ray_setup(o, d);
+    const uint32_t boxes_at_entry = STATS ? st.boxes : 0u;
     // Near bound of the box test: one |tmin| BELOW tmin. Close to the origin the triangle test's t carries
     // an absolute error far above 1e-5*tmin (cancellation in o - v0), so a relative slack is not enough.
     const float t_lo = fminf(tmin, 0.0f) - fabsf(tmin);
@@ -163,6 +164,15 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
         }
         if (sp == 0) node = kSentinel;
         else { sp--; node = stack[sp * stride]; }
+    }
+    if (STATS) {   // diagnostics: remember the most expensive ray of the launch
+        const uint32_t steps = st.boxes - boxes_at_entry;
+        uint32_t* dbg = reinterpret_cast<uint32_t*>(sc.counters) + 16;
+        if (steps > 20000u && atomicMax(dbg, steps) < steps) {
+            float* r = reinterpret_cast<float*>(dbg + 8);
+            r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = tmin; r[4] = d.x; r[5] = d.y; r[6] = d.z; r[7] = tmax;
+            dbg[1] = ANY ? 1u : 0u;
+        }
     }
     return hit.gid != 0xFFFFFFFFu;
 }

@@ -1,0 +1,82 @@
+"""world_size-2 `gloo` test of the tile-parallel path on CPU: the same strip / halo /
+gather code bench.py runs on N GPUs, with the oracle standing in for the HIP kernels. The 2-rank
+result must equal the single-process frame bit for bit over several frames (static camera)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, W, H, frames, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import binding as ob
+    from sunray_amd import abi, distributed as sd, scenes
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    desc = scenes.cornell_box()
+    bn = scenes.white_noise_rgba8()
+    s = ob.OracleScene().load(desc)
+    fr = ob.HostFrame(W, H, bn)
+    cfg = abi.SrTraceConfig.reference()
+    prev = None
+    images = []
+    for f in range(frames):
+        m = ob.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, prev)
+        prev = list(m.view_proj)
+        s.reset_counters()
+        sd.render_strip(s, fr, m, f, cfg, world, rank)
+        full = sd.gather_strips(torch.from_numpy(fr.raw_color), W, H, world, rank)
+        images.append(full.numpy().copy())
+        # max-over-ranks reduction used for timing in bench.py
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == float(world)
+    dist.barrier()
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.stack(images))
+    dist.destroy_process_group()
+
+
+def test_strip_helpers():
+    from sunray_amd import distributed as sd
+    assert [sd.strip_rows(1080, 8, r) for r in range(8)] == [(135 * r, 135) for r in range(8)]
+    assert [sd.strip_rows(10, 4, r) for r in range(4)] == [(0, 3), (3, 3), (6, 3), (9, 1)]
+    assert sd.strip_rows(2, 4, 3) == (2, 0)
+    assert sd.halo_bands(1080, 0, 135) == [(135, 30)]
+    assert sd.halo_bands(1080, 135, 135) == [(105, 30), (270, 30)]
+    assert sd.halo_bands(1080, 945, 135) == [(915, 30)]
+    assert sd.halo_bands(40, 10, 10) == [(0, 10), (20, 20)]
+    assert sd.halo_bands(40, 40, 0) == []
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_equals_single_process(oracle, tmp_path):
+    import torch.multiprocessing as mp
+    W, H, frames = 40, 72, 3   # strips of 36 rows: the 30-row halo does NOT cover the whole image
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, W, H, frames, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(r0.view(np.uint32), r1.view(np.uint32))   # every rank holds the full image
+    from sunray_amd import abi, scenes
+    desc = scenes.cornell_box()
+    s = oracle.OracleScene().load(desc)
+    fr = oracle.HostFrame(W, H, scenes.white_noise_rgba8())
+    prev = None
+    for f in range(frames):
+        m = oracle.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, prev)
+        prev = list(m.view_proj)
+        s.trace_ris(fr, m, f); s.trace_final(fr, m, f)
+        assert np.array_equal(fr.raw_color.view(np.uint32), r0[f].view(np.uint32)), "frame %d" % f
