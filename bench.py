@@ -47,7 +47,8 @@ def cpu_baseline(desc, W, H, blue_noise, budget_s=12.0, max_frames=8):
     """The oracle (our CPU restatement: the reference has no CPU path) timed on this host's cores on
     the same scene / extent / constants; whole frames until ~budget_s of work."""
     from oracle import binding as ob
-    threads = os.cpu_count() or 1
+    threads = ob.usable_cores()   # affinity capped by the cgroup CPU quota (16 on a 1-GPU box)
+    ob.set_threads(threads)
     s = ob.OracleScene().load(desc)
     fr = ob.HostFrame(W, H, blue_noise)
     prev, rays, t_total, frames = None, 0, 0.0, 0

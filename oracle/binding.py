@@ -56,6 +56,22 @@ def lib():
     return _lib
 
 
+def usable_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def set_threads(n):
+    lib().orc_set_threads(C.c_int(n))
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 

@@ -3,12 +3,16 @@
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
 #include <cstring>
 
+#include <omp.h>
+
 #include "orc_scene.h"
 
 using namespace orc;
 
 extern "C" {
 
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int orc_get_max_threads() { return omp_get_max_threads(); }
 void* orc_scene_create() { return new Scene(); }
 void orc_scene_destroy(void* s) { delete (Scene*)s; }
 int orc_scene_add_mesh(void* s, uint64_t key, const SrVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const SrMaterial* m) {

@@ -377,7 +377,7 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
     a.y0 = y0; a.y1 = y1;
     a.tiles_x = (p->width + 15) / 16;
     a.tiles_y = (y1 - y0 + 15) / 16;
-    a.tiles_per_xcd = (a.tiles_x * a.tiles_y + 7) / 8;
+    a.tiles_per_xcd = ((a.tiles_x + 7) / 8) * a.tiles_y;   // widest column band x rows (kernels.hip thread_pixel)
     a.cfg = p->config;
     hipStream_t st = (hipStream_t)stream;
     ScopedTiming tm(s, which == 0 ? kRis : kFinal, st);

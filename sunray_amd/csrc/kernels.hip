@@ -184,11 +184,17 @@ SRD LightTri fetch_light(const DevScene& sc, uint32_t idx) {
 }
 
 // Map this thread to its pixel. Returns false for threads outside the image / tile.
+// XCD-aware and load-balanced: the image is cut into 8 COLUMN bands, one per XCD (blocks b and b+8
+// share an XCD under round-robin dispatch), walked row-major inside the band. Cost varies mostly with
+// image row (distance to the terrain), so column bands give every XCD the same mix of rows, while the
+// tiles an XCD works on at any moment stay neighbours and share its 4 MiB L2.
 SRD bool thread_pixel(const PassArgs& a, uint32_t& px, uint32_t& py) {
     const uint32_t b = blockIdx.x;
-    const uint32_t tile = (b & 7u) * a.tiles_per_xcd + (b >> 3);
-    if (tile >= a.tiles_x * a.tiles_y) return false;
-    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const uint32_t xcd = b & 7u, k = b >> 3;
+    const uint32_t bx0 = (a.tiles_x * xcd) >> 3, bx1 = (a.tiles_x * (xcd + 1u)) >> 3;  // this XCD's tile columns
+    const uint32_t bw = bx1 - bx0;
+    if (bw == 0u || k >= bw * a.tiles_y) return false;
+    const uint32_t tx = bx0 + k % bw, ty = k / bw;
     const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     px = tx * 16u + (w & 1u) * 8u + (l & 7u);
     py = a.y0 + ty * 16u + (w >> 1) * 8u + (l >> 3);

@@ -16,6 +16,7 @@ def pytest_configure(config):
 def oracle():
     from oracle import binding
     binding.build()
+    binding.set_threads(min(binding.usable_cores(), 16))
     return binding
 
 
