@@ -56,7 +56,7 @@ struct SrScene {
     std::vector<SrMeshInfo> mesh_infos;
     srh::FrameInstanceData fid;
     std::vector<srh::BuildTri> world_tris;
-    DeviceBuffer d_nodes, d_tris, d_meshes, d_instances, d_emissive, d_indirection, d_transforms, d_misc;
+    DeviceBuffer d_nodes, d_tris, d_shade, d_mesh_const, d_slot_of_gid, d_instances, d_emissive, d_indirection, d_transforms, d_misc;
     srd::DevScene dev{};
     SrBvhStats stats{};
     bool built = false;
@@ -164,7 +164,7 @@ int sr_scene_destroy(SrScene* s) {
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
     for (auto& m : s->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
-    s->d_nodes.release(); s->d_tris.release(); s->d_meshes.release(); s->d_instances.release();
+    s->d_nodes.release(); s->d_tris.release(); s->d_shade.release(); s->d_mesh_const.release(); s->d_slot_of_gid.release(); s->d_instances.release();
     s->d_emissive.release(); s->d_indirection.release(); s->d_transforms.release(); s->d_misc.release();
     for (auto& pool : s->events) for (auto& e : pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete s;
@@ -227,28 +227,50 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     if (s->emissive_tris.empty()) { SrEmissiveTriangle z; memset(&z, 0, sizeof(z)); s->emissive_tris.push_back(z); }
     srh::flatten_instances(s->meshes, s->fid, s->world_tris);
     srh::BvhResult bvh;
-    srh::build_bvh(s->world_tris, (uint32_t)srd::kStackDepth, bvh);
-    if (bvh.max_depth > (uint32_t)srd::kStackDepth) return fail(SR_ERR_STATE, "BVH depth exceeds the traversal stack");
+    srh::build_bvh(s->world_tris, (uint32_t)srd::kMaxBinaryDepth, bvh);
+    if (bvh.max_stack > (uint32_t)(srd::kStackLds + srd::kStackSpill)) return fail(SR_ERR_STATE, "BVH needs a deeper traversal stack than the kernels provide");
+    // shade records (object-space vertex normals + instance + mesh slot) in leaf order, slot lookup
+    const uint32_t n_tris = s->fid.n_triangles;
+    std::vector<float> shade((size_t)n_tris * 12, 0.0f);
+    std::vector<uint32_t> slot_of_gid(n_tris ? n_tris : 1, 0u);
+    for (uint32_t slot = 0; slot < n_tris; slot++) {
+        const srh::BuildTri& t = s->world_tris[bvh.order[slot]];
+        const srh::HostInstance& inst = s->fid.instances[t.inst];
+        const srh::HostMesh& mesh = s->meshes[inst.mesh_slot];
+        float* q = &shade[(size_t)slot * 12];
+        for (int j = 0; j < 3; j++) memcpy(q + 3 * j, mesh.vertices[mesh.indices[3 * t.prim + j]].normal, 12);
+        memcpy(q + 9, &t.inst, 4);
+        memcpy(q + 10, &inst.mesh_slot, 4);
+        slot_of_gid[t.gid] = slot;
+    }
+    std::vector<srd::DevMeshConst> mconst(s->meshes.size() ? s->meshes.size() : 1);
+    memset(mconst.data(), 0, mconst.size() * sizeof(srd::DevMeshConst));
+    for (size_t i = 0; i < s->meshes.size(); i++) {
+        const SrMaterial& m = s->meshes[i].material;
+        for (int k = 0; k < 3; k++) mconst[i].emission[k] = m.emissive_factor[k] * m.emissive_factor[3];
+        mconst[i].albedo_packed = srh::pack_unorm_4x8(m.base_color_value[0], m.base_color_value[1], m.base_color_value[2], 1.0f);
+        mconst[i].material_info = srh::pack_half_2x16(m.roughness_factor, m.metallic_factor);
+        mconst[i].transmission_ior_packed = srh::pack_half_2x16(m.transmission_factor, m.ior);
+    }
     // device upload (synchronous, like the reference's scene-load BLAS build: blas.rs:178)
     HIP_TRY(hipDeviceSynchronize());
-    std::vector<srd::DevInstance> dinst(s->fid.instances.size());
-    for (size_t i = 0; i < dinst.size(); i++) {
-        memcpy(dinst[i].o2w, s->fid.instances[i].o2w.m, 48);
-        memcpy(dinst[i].w2o, s->fid.instances[i].w2o, 36);
-        dinst[i].mesh_slot = s->fid.instances[i].mesh_slot;
-        dinst[i].tri_offset = s->fid.instances[i].tri_offset;
-        dinst[i]._pad = 0;
-    }
+    std::vector<srd::DevInstance> dinst(s->fid.instances.size() ? s->fid.instances.size() : 1);
+    memset(dinst.data(), 0, dinst.size() * sizeof(srd::DevInstance));
+    for (size_t i = 0; i < s->fid.instances.size(); i++) memcpy(dinst[i].w2o, s->fid.instances[i].w2o, 36);
     if ((rc = s->d_nodes.upload(bvh.nodes.data(), bvh.nodes.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_tris.upload(bvh.tris.data(), bvh.tris.size() * 4)) != SR_OK) return rc;
-    if ((rc = s->d_meshes.upload(s->mesh_infos.data(), s->mesh_infos.size() * sizeof(SrMeshInfo))) != SR_OK) return rc;
+    if ((rc = s->d_shade.upload(shade.data(), shade.size() * 4)) != SR_OK) return rc;
+    if ((rc = s->d_slot_of_gid.upload(slot_of_gid.data(), slot_of_gid.size() * 4)) != SR_OK) return rc;
+    if ((rc = s->d_mesh_const.upload(mconst.data(), mconst.size() * sizeof(srd::DevMeshConst))) != SR_OK) return rc;
     if ((rc = s->d_instances.upload(dinst.data(), dinst.size() * sizeof(srd::DevInstance))) != SR_OK) return rc;
     if ((rc = s->d_emissive.upload(s->emissive_tris.data(), s->emissive_tris.size() * sizeof(SrEmissiveTriangle))) != SR_OK) return rc;
     if ((rc = s->d_indirection.upload(s->fid.emissive_entries.data(), s->fid.emissive_entries.size() * sizeof(SrEmissiveIndirectionEntry))) != SR_OK) return rc;
     if ((rc = s->d_transforms.upload(s->fid.transforms.data(), s->fid.transforms.size() * sizeof(SrTransform))) != SR_OK) return rc;
     s->dev.nodes = (const float4*)s->d_nodes.p;
     s->dev.tris = (const float4*)s->d_tris.p;
-    s->dev.meshes = (const SrMeshInfo*)s->d_meshes.p;
+    s->dev.shade = (const float4*)s->d_shade.p;
+    s->dev.mesh_const = (const srd::DevMeshConst*)s->d_mesh_const.p;
+    s->dev.slot_of_gid = (const uint32_t*)s->d_slot_of_gid.p;
     s->dev.instances = (const srd::DevInstance*)s->d_instances.p;
     s->dev.emissive = (const SrEmissiveTriangle*)s->d_emissive.p;
     s->dev.indirection = (const SrEmissiveIndirectionEntry*)s->d_indirection.p;
@@ -259,7 +281,7 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     s->dev.n_instances = (uint32_t)s->fid.instances.size();
     s->stats.n_triangles = s->fid.n_triangles;
     s->stats.n_nodes = bvh.n_nodes;
-    s->stats.node_bytes = (uint64_t)bvh.n_nodes * 64;
+    s->stats.node_bytes = (uint64_t)bvh.n_nodes * 128;
     s->stats.tri_bytes = (uint64_t)s->fid.n_triangles * 48;
     s->stats.max_depth = bvh.max_depth;
     s->stats.sah_cost = bvh.sah_cost;
@@ -465,11 +487,11 @@ int sr_host_bvh_build(const float* v, uint32_t n, SrHostBvh** out) {
     }
     auto* h = new SrHostBvhImpl();
     h->n = n;
-    srh::build_bvh(t, (uint32_t)srd::kStackDepth, h->r);
+    srh::build_bvh(t, (uint32_t)srd::kMaxBinaryDepth, h->r);
     *out = reinterpret_cast<SrHostBvh*>(h);
     return SR_OK;
 }
-int sr_host_bvh_get(const SrHostBvh* bvh, const float** nodes, uint32_t* n_nodes, const float** tris, uint32_t* n_triangles, uint32_t* max_depth) {
+int sr_host_bvh_get(const SrHostBvh* bvh, const float** nodes, uint32_t* n_nodes, const float** tris, uint32_t* n_triangles, uint32_t* max_depth, uint32_t* max_stack) {
     if (!bvh) return fail(SR_ERR_INVALID_ARG, "sr_host_bvh_get: null handle");
     const auto* h = reinterpret_cast<const SrHostBvhImpl*>(bvh);
     if (nodes) *nodes = h->r.nodes.data();
@@ -477,6 +499,7 @@ int sr_host_bvh_get(const SrHostBvh* bvh, const float** nodes, uint32_t* n_nodes
     if (tris) *tris = h->r.tris.data();
     if (n_triangles) *n_triangles = h->n;
     if (max_depth) *max_depth = h->r.max_depth;
+    if (max_stack) *max_stack = h->r.max_stack;
     return SR_OK;
 }
 int sr_host_bvh_destroy(SrHostBvh* bvh) { delete reinterpret_cast<SrHostBvhImpl*>(bvh); return SR_OK; }

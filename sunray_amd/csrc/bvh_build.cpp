@@ -203,6 +203,83 @@ struct Builder {
 
 }  // namespace
 
+// Collapse the binary tree into a 4-wide tree: a node adopts its two children, then repeatedly
+// replaces the inner child with the largest surface area by that child's two children until it has
+// four (or only leaves are left). One 128-byte node per step halves the number of dependent memory
+// round trips of a traversal, which is what bounds the kernels.
+// Node layout (32 floats): lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] child[4] pad[4];
+// unused children have an empty box (lo = +inf, hi = -inf) and an empty-leaf reference.
+namespace {
+struct Child4 { float lo[3], hi[3]; int ref; };
+inline Child4 child_of(const float* n2, int which) {
+    Child4 c;
+    if (which == 0) { c.lo[0] = n2[0]; c.hi[0] = n2[1]; c.lo[1] = n2[2]; c.hi[1] = n2[3]; c.lo[2] = n2[8]; c.hi[2] = n2[9]; }
+    else { c.lo[0] = n2[4]; c.hi[0] = n2[5]; c.lo[1] = n2[6]; c.hi[1] = n2[7]; c.lo[2] = n2[10]; c.hi[2] = n2[11]; }
+    memcpy(&c.ref, n2 + 12 + which, 4);
+    return c;
+}
+inline float area_of(const Child4& c) {
+    const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+    if (!(dx >= 0.0f)) return -1.0f;
+    return dx * dy + dy * dz + dz * dx;
+}
+struct Collapser {
+    const std::vector<float>& n2;
+    std::vector<float>& out;
+    uint32_t max_depth = 0;
+    // returns the worst-case number of stack entries a traversal below (and including) this node needs
+    uint32_t emit(int node2, uint32_t depth, int* out_index) {
+        Child4 kids[4];
+        int nk = 0;
+        kids[nk++] = child_of(&n2[(size_t)node2 * 16], 0);
+        kids[nk++] = child_of(&n2[(size_t)node2 * 16], 1);
+        while (nk < 4) {
+            int best = -1; float best_area = -1.0f;
+            for (int i = 0; i < nk; i++) if (kids[i].ref >= 0) { const float a = area_of(kids[i]); if (a > best_area) { best_area = a; best = i; } }
+            if (best < 0) break;
+            const int inner = kids[best].ref;
+            kids[best] = child_of(&n2[(size_t)inner * 16], 0);
+            kids[nk++] = child_of(&n2[(size_t)inner * 16], 1);
+        }
+        const size_t self = out.size();
+        *out_index = (int)(self / 32);
+        out.resize(self + 32, 0.0f);
+        max_depth = std::max(max_depth, depth);
+        uint32_t below = 0;
+        int n_real = 0;
+        for (int i = 0; i < 4; i++) {
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int ref = Builder::leaf_ref(0, 0);
+            if (i < nk) {
+                const bool empty_leaf = kids[i].ref < 0 && ((~(uint32_t)kids[i].ref) & 7u) == 0u;
+                if (!empty_leaf) {
+                    n_real++;
+                    memcpy(lo, kids[i].lo, 12); memcpy(hi, kids[i].hi, 12);
+                    if (kids[i].ref >= 0) {
+                        int idx = 0;
+                        below = std::max(below, emit(kids[i].ref, depth + 1, &idx));
+                        ref = idx;
+                    } else ref = kids[i].ref;
+                }
+            }
+            float* q = &out[self];
+            q[0 + i] = lo[0]; q[4 + i] = hi[0]; q[8 + i] = lo[1]; q[12 + i] = hi[1]; q[16 + i] = lo[2]; q[20 + i] = hi[2];
+            memcpy(q + 24 + i, &ref, 4);
+        }
+        return below + (uint32_t)std::max(n_real - 1, 0);
+    }
+};
+}  // namespace
+
+static void collapse_to_bvh4(BvhResult& res) {
+    res.nodes.clear();
+    Collapser c{res.nodes2, res.nodes};
+    int root = 0;
+    res.max_stack = c.emit(0, 1, &root);
+    res.max_depth = c.max_depth;
+    res.n_nodes = (uint32_t)(res.nodes.size() / 32);
+}
+
 void flatten_instances(const std::vector<HostMesh>& meshes, const FrameInstanceData& fid, std::vector<BuildTri>& out) {
     out.clear();
     out.reserve(fid.n_triangles);
@@ -269,10 +346,10 @@ void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult&
     } else {
         b.build_sub(0, n, 0, top);
     }
-    res.nodes.swap(top.nodes);
-    res.n_nodes = (uint32_t)(res.nodes.size() / 16);
-    res.max_depth = top.depth;
+    res.nodes2.swap(top.nodes);
     res.sah_cost = (float)top.cost;
+    collapse_to_bvh4(res);
+    res.order = b.order;
     res.tris.resize((size_t)n * 12);
     for (uint32_t i = 0; i < n; i++) {
         const BuildTri& t = tris[b.order[i]];
@@ -280,7 +357,8 @@ void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult&
         q[0] = t.v0[0]; q[1] = t.v0[1]; q[2] = t.v0[2]; q[3] = t.e1[0];
         q[4] = t.e1[1]; q[5] = t.e1[2]; q[6] = t.e2[0]; q[7] = t.e2[1];
         q[8] = t.e2[2];
-        memcpy(q + 9, &t.prim, 4); memcpy(q + 10, &t.inst, 4); memcpy(q + 11, &t.gid, 4);
+        memcpy(q + 9, &t.gid, 4);
+        q[10] = 0.0f; q[11] = 0.0f;
     }
     res.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
 }

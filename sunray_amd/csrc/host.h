@@ -49,6 +49,9 @@ void material_new(const float base_color[4], float metallic, float roughness, co
 void emissive_triangles_from_mesh(const SrVertex* vertices, const uint32_t* indices, uint32_t n_indices,
                                   const SrMaterial& material, std::vector<SrEmissiveTriangle>& out);
 void world_to_object_3x3(const SrTransform& t, float out[9]);
+// Host twins of the shader pack helpers (rt_utils.slang:77-94), used to pre-pack per-mesh payload constants.
+uint32_t pack_unorm_4x8(float x, float y, float z, float w);
+uint32_t pack_half_2x16(float x, float y);
 bool frame_instance_data(const std::vector<HostMesh>& meshes, const std::map<uint64_t, uint32_t>& slots,
                          const uint64_t* keys, const uint32_t* counts, uint32_t n_keys, const SrTransform* xforms,
                          FrameInstanceData& out, std::string& err);
@@ -60,15 +63,18 @@ struct BuildTri {
     uint32_t prim, inst, gid;
 };
 struct BvhResult {
-    std::vector<float> nodes;  // 16 floats (64 B) per inner node
+    std::vector<float> nodes2; // intermediate binary tree: 16 floats per inner node (two child boxes)
+    std::vector<float> nodes;  // the 4-wide tree the kernels traverse: 32 floats (128 B) per node
     std::vector<float> tris;   // 12 floats (48 B) per triangle, leaf order
-    uint32_t n_nodes = 0, max_depth = 0;
+    std::vector<uint32_t> order;  // leaf slot -> index into the input triangle list
+    uint32_t n_nodes = 0, max_depth = 0, max_stack = 0;
     float sah_cost = 0.0f;
     double build_ms = 0.0;
 };
 // Flatten every instance's triangles to world space (instance-major order = global triangle index).
 void flatten_instances(const std::vector<HostMesh>& meshes, const FrameInstanceData& fid, std::vector<BuildTri>& out);
-// Binned-SAH BVH2 with depth bounded by `max_depth`, leaves of <= 4 triangles.
+// Binned-SAH binary tree with depth bounded by `max_depth`, leaves of <= 4 triangles, collapsed into a
+// 4-wide BVH (layout: traverse.h). max_stack = worst-case traversal stack entries for this tree.
 void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult& out);
 
 }  // namespace srh

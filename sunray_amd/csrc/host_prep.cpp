@@ -131,6 +131,28 @@ void world_to_object_3x3(const SrTransform& t, float o[9]) {
     o[6] = c02 * r; o[7] = (a01 * a20 - a00 * a21) * r; o[8] = (a00 * a11 - a01 * a10) * r;
 }
 
+// pack_unorm_4x8 / pack_half_2x16 (rt_utils.slang:77-94) on the host: round-half-even, IEEE binary16 RNE
+static uint32_t unorm8(float v) {
+    const float c = fminf(fmaxf(v, 0.0f), 1.0f);
+    return (uint32_t)rintf(c * 255.0f);
+}
+uint32_t pack_unorm_4x8(float x, float y, float z, float w) { return unorm8(x) | (unorm8(y) << 8) | (unorm8(z) << 16) | (unorm8(w) << 24); }
+static uint32_t half_bits(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u > 0x7f800000u) return sign | 0x7e00u | ((u >> 13) & 0x3ffu);
+    if (u >= 0x477ff000u) return sign | 0x7c00u;
+    if (u >= 0x38800000u) { uint32_t t = u - 0x38000000u; t += 0xfffu + ((t >> 13) & 1u); return sign | (t >> 13); }
+    if (u < 0x33000000u) return sign;
+    const uint32_t e = u >> 23, m = (u & 0x7fffffu) | 0x800000u, sh = 126u - e;
+    uint32_t h = m >> sh;
+    const uint32_t lower = m & ((1u << sh) - 1u), half = 1u << (sh - 1u);
+    if (lower > half || (lower == half && (h & 1u))) h++;
+    return sign | h;
+}
+uint32_t pack_half_2x16(float x, float y) { return half_bits(x) | (half_bits(y) << 16); }
+
 // ResourceManager::frame_instance_data (resource_manager.rs:216-267) followed by the dummy-entry
 // padding of Renderer::render (lib.rs:1058-1081).
 bool frame_instance_data(const std::vector<HostMesh>& meshes, const std::map<uint64_t, uint32_t>& slots,

@@ -30,7 +30,7 @@ template <bool ANY, bool STATS>
 __global__ __launch_bounds__(kBlock) void trace_queue_kernel(DevScene sc, const SrRay* __restrict__ rays, uint32_t n,
                                                              SrHit* __restrict__ hits, uint32_t* __restrict__ occluded,
                                                              uint32_t* __restrict__ queue_head) {
-    __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ int s_stack[kStackLds * kBlock];
     const int lane = threadIdx.x & 63;
     int* stack = s_stack + threadIdx.x;
     uint32_t n_queries = 0;
@@ -65,14 +65,8 @@ __global__ __launch_bounds__(kBlock) void shade_closest_hit_kernel(DevScene sc, 
     if (i >= n) return;
     const SrHit h = hits[i];
     TravHit th;
-    th.t = h.t; th.u = h.u; th.v = h.v; th.gid = (h.t < 0.0f) ? 0xFFFFFFFFu : h.tri; th.prim = 0; th.inst = 0;
-    if (th.gid != 0xFFFFFFFFu) {
-        // global triangle index -> (instance, primitive): instances are few; binary search the offsets
-        uint32_t lo = 0, hi = sc.n_instances;
-        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sc.instances[mid].tri_offset <= th.gid) lo = mid; else hi = mid; }
-        th.inst = lo;
-        th.prim = th.gid - sc.instances[lo].tri_offset;
-    }
+    th.t = h.t; th.u = h.u; th.v = h.v; th.gid = (h.t < 0.0f || h.tri >= sc.n_tris) ? 0xFFFFFFFFu : h.tri;
+    th.slot = (th.gid != 0xFFFFFFFFu) ? sc.slot_of_gid[th.gid] : 0u;
     const Payload p = shade_hit(sc, th);
     SrRayPayload o;
     o.emission[0] = p.emission.x; o.emission[1] = p.emission.y; o.emission[2] = p.emission.z;
@@ -203,7 +197,7 @@ SRD bool thread_pixel(const PassArgs& a, uint32_t& px, uint32_t& py) {
 
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
-    __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ int s_stack[kStackLds * kBlock];
     PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
     const DevScene& sc = a.sc;
     uint32_t px = 0, py = 0;
@@ -445,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
 
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
-    __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ int s_stack[kStackLds * kBlock];
     PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
     const DevScene& sc = a.sc;
     uint32_t px = 0, py = 0;

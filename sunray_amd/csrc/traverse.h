@@ -3,39 +3,51 @@
 // ray_gen_final.slang:80,212,283,316,370).
 //
 // Data layout in HBM:
-//   nodes : 64 B per inner node = 4 x float4
-//           n0 = (c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y)   n1 = (c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y)
-//           n2 = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)   n3 = (child0, child1, -, -) as int bits
-//           child >= 0: inner node index; child < 0: leaf, ~child = (first_triangle << 3) | count
-//   tris  : 48 B per triangle = 3 x float4, stored in leaf order
-//           t0 = (v0.x, v0.y, v0.z, e1.x)  t1 = (e1.y, e1.z, e2.x, e2.y)
-//           t2 = (e2.z, primitive index, instance index, global triangle index) (last three as bits)
+//   nodes : 4-wide BVH, one 128-byte node (= one L2 line) per step: 8 x float4
+//           [0] lo.x[4] [1] hi.x[4] [2] lo.y[4] [3] hi.y[4] [4] lo.z[4] [5] hi.z[4] [6] child[4] [7] pad
+//           child >= 0: node index; child < 0: leaf, ~child = (first_triangle << 3) | count;
+//           an unused child has lo = +inf, hi = -inf (nothing hits it) and an empty leaf reference.
+//           A lane reads the NEAR plane of an axis straight from lo or hi by its ray's sign — the
+//           loads are per-lane gathers anyway, so ordering the slabs costs no select instructions.
+//   tris  : 48 B per triangle = 3 x float4, in leaf order:
+//           (v0.x, v0.y, v0.z, e1.x) (e1.y, e1.z, e2.x, e2.y) (e2.z, global triangle index, -, -)
+//   shade : 48 B per triangle, same order, read once per committed closest hit:
+//           (n0.x, n0.y, n0.z, n1.x) (n1.y, n1.z, n2.x, n2.y) (n2.z, instance index, mesh slot, -)
+//           (object-space vertex normals: the only vertex attribute closest_hit needs without textures)
 // One lane = one ray. The per-lane traversal stack lives in LDS, interleaved as stack[level][lane]
-// so a wave's pushes/pops hit 64 consecutive banks (conflict-free ds_write_b32 / ds_read_b32).
+// so a wave's pushes/pops hit 64 consecutive banks (conflict-free ds_write_b32 / ds_read_b32); the
+// rare entries beyond kStackLds spill to a private array.
 #pragma once
 #include "rt_device.h"
 
 namespace srd {
 
-constexpr int kStackDepth = 32;      // the builder bounds the tree depth to this (bvh_build.cpp)
+constexpr int kStackLds = 24;        // LDS stack entries per lane (24 KB per 256-thread workgroup)
+constexpr int kStackSpill = 72;      // private overflow; the builder checks max_stack <= kStackLds + kStackSpill
+constexpr int kMaxBinaryDepth = 32;  // depth bound of the binary tree the 4-wide tree is collapsed from
 constexpr int kSentinel = 0x7fffffff;
 
-struct DevInstance {   // 96 B
-    float o2w[12];     // ObjectToWorld3x4 (row-major)
-    float w2o[9];      // (float3x3)WorldToObject3x4
-    uint32_t mesh_slot;
-    uint32_t tri_offset;
-    uint32_t _pad;
+struct DevInstance {   // 48 B: (float3x3)WorldToObject3x4, row-major, padded to 3 x float4
+    float w2o[12];
+};
+struct DevMeshConst {  // 32 B: the per-mesh constants of the 32-byte RayPayload (no textures in scope)
+    float emission[3];           // emissive_factor.rgb * strength      (closest_hit.slang:43-46)
+    uint32_t albedo_packed;      // pack_unorm_4x8(base_color.rgb, 1)   (:76)
+    uint32_t material_info;      // pack_half_2x16(roughness, metallic) (:79-89)
+    uint32_t transmission_ior_packed;  // (:90)
+    uint32_t _pad[2];
 };
 
 struct DevScene {
     const float4* nodes;
     const float4* tris;
-    const SrMeshInfo* meshes;
+    const float4* shade;
+    const DevMeshConst* mesh_const;
     const DevInstance* instances;
     const SrEmissiveTriangle* emissive;
     const SrEmissiveIndirectionEntry* indirection;
     const SrTransform* transforms;
+    const uint32_t* slot_of_gid;   // global triangle index -> leaf-order slot (sr_shade_closest_hit only)
     unsigned long long* counters;  // [0]=closest queries [1]=any queries [2]=boxes [3]=tris
     uint32_t num_lights;
     uint32_t n_tris;
@@ -45,7 +57,7 @@ struct DevScene {
 
 struct TravHit {
     float t, u, v;
-    uint32_t prim, inst, gid;  // gid == 0xFFFFFFFF: miss
+    uint32_t gid, slot;  // gid == 0xFFFFFFFF: miss; slot = position in tris/shade
 };
 
 struct TravStats { uint32_t boxes, tris; };
@@ -71,38 +83,56 @@ SRD bool intersect_tri(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax, 
     return (u >= -kBaryEps) && (v >= -kBaryEps) && (u + v <= 1.0f + kBaryEps) && (t > tmin) && (t < tmax);
 }
 
-// Conservative slab test: a box is only rejected if no triangle hit with t in (t_lo, t_hi] can lie
-// inside it. Planes are taken in the ray's own order (near plane = hi for a negative direction), so
-// a zero direction component yields -inf/+inf inside the slab and NaN exactly on a face; v_max/v_min
-// (IEEE maxNum/minNum) drop the NaN, i.e. slabs are closed. The far side is inflated (Ize 2013).
+// Conservative slab tests: a box is only rejected if no triangle hit with t in
+// (t_lo, t_hi] can lie inside it. Planes are taken in the ray's own order, so a zero direction
+// component yields -inf/+inf inside the slab and NaN exactly on a face; v_max/v_min (IEEE
+// maxNum/minNum) drop the NaN, i.e. slabs are closed. The far side is inflated (Ize 2013).
 struct RaySetup {
     f3 o, inv;
-    bool sx, sy, sz;
+    int nx, ny, nz;   // float4 index of the NEAR plane array of each axis inside a node (far = the other)
+    int fx, fy, fz;
 };
 SRD RaySetup ray_setup(f3 o, f3 d) {
     RaySetup r;
     r.o = o;
     r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    r.sx = (__float_as_uint(r.inv.x) >> 31) != 0u;
-    r.sy = (__float_as_uint(r.inv.y) >> 31) != 0u;
-    r.sz = (__float_as_uint(r.inv.z) >> 31) != 0u;
+    const int sx = (int)(__float_as_uint(r.inv.x) >> 31), sy = (int)(__float_as_uint(r.inv.y) >> 31), sz = (int)(__float_as_uint(r.inv.z) >> 31);
+    r.nx = 0 + sx; r.fx = 1 - sx;
+    r.ny = 2 + sy; r.fy = 3 - sy;
+    r.nz = 4 + sz; r.fz = 5 - sz;
     return r;
 }
-SRD bool slab(float lox, float hix, float loy, float hiy, float loz, float hiz, const RaySetup& r, float t_lo, float t_hi, float& tnear) {
-    const float nx = ((r.sx ? hix : lox) - r.o.x) * r.inv.x, fx = ((r.sx ? lox : hix) - r.o.x) * r.inv.x;
-    const float ny = ((r.sy ? hiy : loy) - r.o.y) * r.inv.y, fy = ((r.sy ? loy : hiy) - r.o.y) * r.inv.y;
-    const float nz = ((r.sz ? hiz : loz) - r.o.z) * r.inv.z, fz = ((r.sz ? loz : hiz) - r.o.z) * r.inv.z;
-    const float t0 = fmaxf(fmaxf(nx, ny), fmaxf(nz, t_lo));
-    float far = fminf(fminf(fx, fy), fz);
+SRD float slab_near(float px, float py, float pz, const RaySetup& r, float t_lo) {
+    return fmaxf(fmaxf((px - r.o.x) * r.inv.x, (py - r.o.y) * r.inv.y), fmaxf((pz - r.o.z) * r.inv.z, t_lo));
+}
+SRD float slab_far(float px, float py, float pz, const RaySetup& r, float t_hi) {
+    float far = fminf(fminf((px - r.o.x) * r.inv.x, (py - r.o.y) * r.inv.y), (pz - r.o.z) * r.inv.z);
     far = far * (1.0f + copysignf(5e-7f, far));  // away from zero; keeps +-inf (an fma form turns -inf into NaN)
-    const float t1 = fminf(far, t_hi);
-    tnear = t0;
-    return t0 <= t1;
+    return fminf(far, t_hi);
 }
 
-// stack: this lane's column of the LDS stack (element k at stack[k * stride]).
+struct Stack {
+    int* lds;       // this lane's column: element k at lds[k * stride]
+    int stride;
+    int spill[kStackSpill];
+    int sp;
+    SRD void push(int v) {
+        if (sp < kStackLds) lds[sp * stride] = v;
+        else spill[sp - kStackLds] = v;
+        sp++;
+    }
+    SRD int pop() {
+        if (sp == 0) return kSentinel;
+        sp--;
+        return sp < kStackLds ? lds[sp * stride] : spill[sp - kStackLds];
+    }
+};
+
+SRD int pick(int4 c, uint32_t i) { return i == 0u ? c.x : (i == 1u ? c.y : (i == 2u ? c.z : c.w)); }
+SRD void cswap(uint32_t& a, uint32_t& b) { const uint32_t lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
+
 template <bool ANY, bool STATS>
-SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHit& hit, int* stack, int stride, TravStats& st) {
+SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHit& hit, int* stack_lds, int stride, TravStats& st) {
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ tris = sc.tris;
     const RaySetup rs = ray_setup(o, d);
@@ -113,32 +143,42 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
     // Box culling bounds are relaxed on both ends; only the triangle test applies the exact (tmin, tmax).
     float cull = fmaf(fabsf(tmax), 1e-5f, tmax);
     float best_t = tmax;
-    hit.t = -1.0f; hit.u = 0.0f; hit.v = 0.0f; hit.prim = 0; hit.inst = 0; hit.gid = 0xFFFFFFFFu;
-    int sp = 0;
+    hit.t = -1.0f; hit.u = 0.0f; hit.v = 0.0f; hit.gid = 0xFFFFFFFFu; hit.slot = 0u;
+    Stack stk;
+    stk.lds = stack_lds; stk.stride = stride; stk.sp = 0;
     int node = 0;  // the root is always inner node 0
     while (node != kSentinel) {
         while (node >= 0 && node != kSentinel) {
-            const float4 n0 = nodes[node * 4 + 0];
-            const float4 n1 = nodes[node * 4 + 1];
-            const float4 n2 = nodes[node * 4 + 2];
-            const float4 n3 = nodes[node * 4 + 3];
-            float tn0, tn1;
-            const bool h0 = slab(n0.x, n0.y, n0.z, n0.w, n2.x, n2.y, rs, t_lo, cull, tn0);
-            const bool h1 = slab(n1.x, n1.y, n1.z, n1.w, n2.z, n2.w, rs, t_lo, cull, tn1);
-            if (STATS) st.boxes += 2;
-            int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-            if (h0 && h1) {
-                if (tn1 < tn0) { int t = c0; c0 = c1; c1 = t; }
-                stack[sp * stride] = c1;
-                sp++;
-                node = c0;
-            } else if (h0) {
-                node = c0;
-            } else if (h1) {
-                node = c1;
+            const float4* n = nodes + (size_t)node * 8;
+            const float4 qnx = n[rs.nx], qfx = n[rs.fx], qny = n[rs.ny], qfy = n[rs.fy], qnz = n[rs.nz], qfz = n[rs.fz];
+            const float4 qc = n[6];
+            const int4 child = make_int4(__float_as_int(qc.x), __float_as_int(qc.y), __float_as_int(qc.z), __float_as_int(qc.w));
+            if (STATS) st.boxes += 4;
+            const float n0 = slab_near(qnx.x, qny.x, qnz.x, rs, t_lo), f0 = slab_far(qfx.x, qfy.x, qfz.x, rs, cull);
+            const float n1 = slab_near(qnx.y, qny.y, qnz.y, rs, t_lo), f1 = slab_far(qfx.y, qfy.y, qfz.y, rs, cull);
+            const float n2 = slab_near(qnx.z, qny.z, qnz.z, rs, t_lo), f2 = slab_far(qfx.z, qfy.z, qfz.z, rs, cull);
+            const float n3 = slab_near(qnx.w, qny.w, qnz.w, rs, t_lo), f3_ = slab_far(qfx.w, qfy.w, qfz.w, rs, cull);
+            if (ANY) {
+                // order is irrelevant for an existence query: continue with the first hit child, push the rest
+                int next = kSentinel;
+                bool have = false;
+                if (n0 <= f0) { next = child.x; have = true; }
+                if (n1 <= f1) { if (have) stk.push(child.y); else { next = child.y; have = true; } }
+                if (n2 <= f2) { if (have) stk.push(child.z); else { next = child.z; have = true; } }
+                if (n3 <= f3_) { if (have) stk.push(child.w); else { next = child.w; have = true; } }
+                node = have ? next : stk.pop();
             } else {
-                if (sp == 0) node = kSentinel;
-                else { sp--; node = stack[sp * stride]; }
+                // sort the hit children near-to-far: key = entry distance (clamped to >= 0, low 2 mantissa
+                // bits replaced by the child slot) — positive floats order like unsigned integers
+                uint32_t k0 = (n0 <= f0) ? ((__float_as_uint(fmaxf(n0, 0.0f)) & ~3u) | 0u) : 0xFFFFFFFFu;
+                uint32_t k1 = (n1 <= f1) ? ((__float_as_uint(fmaxf(n1, 0.0f)) & ~3u) | 1u) : 0xFFFFFFFFu;
+                uint32_t k2 = (n2 <= f2) ? ((__float_as_uint(fmaxf(n2, 0.0f)) & ~3u) | 2u) : 0xFFFFFFFFu;
+                uint32_t k3 = (n3 <= f3_) ? ((__float_as_uint(fmaxf(n3, 0.0f)) & ~3u) | 3u) : 0xFFFFFFFFu;
+                cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
+                if (k3 != 0xFFFFFFFFu) stk.push(pick(child, k3 & 3u));
+                if (k2 != 0xFFFFFFFFu) stk.push(pick(child, k2 & 3u));
+                if (k1 != 0xFFFFFFFFu) stk.push(pick(child, k1 & 3u));
+                node = (k0 != 0xFFFFFFFFu) ? pick(child, k0 & 3u) : stk.pop();
             }
         }
         if (node == kSentinel) break;
@@ -146,24 +186,23 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
         const uint32_t lv = ~(uint32_t)node;
         const uint32_t first = lv >> 3, cnt = lv & 7u;
         for (uint32_t i = 0; i < cnt; i++) {
-            const float4 t0 = tris[(first + i) * 3 + 0];
-            const float4 t1 = tris[(first + i) * 3 + 1];
-            const float4 t2 = tris[(first + i) * 3 + 2];
+            const float4 t0 = tris[(size_t)(first + i) * 3 + 0];
+            const float4 t1 = tris[(size_t)(first + i) * 3 + 1];
+            const float4 t2 = tris[(size_t)(first + i) * 3 + 2];
             float t, u, v;
             if (STATS) st.tris += 1;
             if (intersect_tri(o, d, mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), tmin, tmax, t, u, v)) {
                 if (ANY) return true;
-                const uint32_t gid = __float_as_uint(t2.w);
+                const uint32_t gid = __float_as_uint(t2.y);
                 if (t < best_t || (t == best_t && gid < hit.gid)) {
                     best_t = t;
                     hit.t = t; hit.u = u; hit.v = v;
-                    hit.prim = __float_as_uint(t2.y); hit.inst = __float_as_uint(t2.z); hit.gid = gid;
+                    hit.gid = gid; hit.slot = first + i;
                     cull = fmaf(fabsf(t), 1e-5f, t);
                 }
             }
         }
-        if (sp == 0) node = kSentinel;
-        else { sp--; node = stack[sp * stride]; }
+        node = stk.pop();
     }
     if (STATS) {   // diagnostics: remember the most expensive ray of the launch
         const uint32_t steps = st.boxes - boxes_at_entry;
@@ -185,34 +224,33 @@ struct Payload {
 };
 
 // closest_hit.slang:12-91 for NULL-texture materials (sample_texture returns its fallback,
-// rt_utils.slang:127-129); ray_miss.slang:10-13 for misses.
+// rt_utils.slang:127-129), ray_miss.slang:10-13 for misses. Without textures the payload needs one
+// vertex attribute (the normal) plus per-mesh constants: one 48-byte shade record, the instance's
+// WorldToObject and a 32-byte DevMeshConst, instead of the reference's MeshInfo -> indices -> vertices
+// pointer chase (4 dependent fetches).
 SRD Payload shade_hit(const DevScene& sc, const TravHit& h) {
     Payload pl;
     pl.emission = splat(0.0f);
     pl.albedo_packed = 0; pl.normal_packed = 0; pl.material_info = 0; pl.transmission_ior_packed = 0;
     if (h.gid == 0xFFFFFFFFu) { pl.dist = -1.0f; return pl; }
-    const DevInstance* inst = sc.instances + h.inst;
-    const SrMeshInfo* mi = sc.meshes + inst->mesh_slot;
-    const SrVertex* verts = (const SrVertex*)mi->vertices;
-    const uint32_t* idx = (const uint32_t*)mi->indices;
-    const uint32_t io = h.prim * 3;
-    const uint32_t i0 = idx[io + 0], i1 = idx[io + 1], i2 = idx[io + 2];
+    const float4 s0 = sc.shade[(size_t)h.slot * 3 + 0];
+    const float4 s1 = sc.shade[(size_t)h.slot * 3 + 1];
+    const float4 s2 = sc.shade[(size_t)h.slot * 3 + 2];
+    const uint32_t inst = __float_as_uint(s2.y), mesh = __float_as_uint(s2.z);
     const f3 bary = mk3(1.0f - h.u - h.v, h.u, h.v);
-    const f3 na = ld3(verts[i0].normal), nb = ld3(verts[i1].normal), nc = ld3(verts[i2].normal);
+    const f3 na = mk3(s0.x, s0.y, s0.z), nb = mk3(s0.w, s1.x, s1.y), nc = mk3(s1.z, s1.w, s2.x);
     const f3 normal = na * bary.x + nb * bary.y + nc * bary.z;
-    const SrMaterial& m = mi->material;
-    const f3 base_color = mk3(m.base_color_value[0], m.base_color_value[1], m.base_color_value[2]);
-    const f3 final_emission = mk3(m.emissive_factor[0], m.emissive_factor[1], m.emissive_factor[2]) * m.emissive_factor[3];
-    const float* W = inst->w2o;
+    const float* W = sc.instances[inst].w2o;
     const f3 world_normal = norm3(mk3((normal.x * W[0] + normal.y * W[3]) + normal.z * W[6],
                                       (normal.x * W[1] + normal.y * W[4]) + normal.z * W[7],
                                       (normal.x * W[2] + normal.y * W[5]) + normal.z * W[8]));
+    const DevMeshConst mc = sc.mesh_const[mesh];
     pl.dist = h.t;
-    pl.emission = final_emission;
-    pl.albedo_packed = pack_unorm_4x8(base_color.x, base_color.y, base_color.z, 1.0f);
+    pl.emission = mk3(mc.emission[0], mc.emission[1], mc.emission[2]);
+    pl.albedo_packed = mc.albedo_packed;
     pl.normal_packed = pack_normal(world_normal);
-    pl.material_info = pack_half_2x16(m.roughness_factor, m.metallic_factor);
-    pl.transmission_ior_packed = pack_half_2x16(m.transmission_factor, m.ior);
+    pl.material_info = mc.material_info;
+    pl.transmission_ior_packed = mc.transmission_ior_packed;
     return pl;
 }
 

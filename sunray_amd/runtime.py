@@ -48,19 +48,19 @@ def emissive_triangles_from_mesh(vertices, indices, material):
 
 
 def host_bvh(v0_e1_e2):
-    """Host-only BVH build (no GPU): returns (nodes[n,16] f32, tris[n,12] f32, max_depth)."""
+    """Host-only BVH build (no GPU): returns (nodes[n,32] f32, tris[n,12] f32, max_depth, max_stack)."""
     v = np.ascontiguousarray(v0_e1_e2, dtype=np.float32).reshape(-1, 9)
     h = C.c_void_p()
     check(lib().sr_host_bvh_build(_p(v), C.c_uint32(len(v)), C.byref(h)))
     try:
         np_, tp = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
-        nn, nt, md = C.c_uint32(), C.c_uint32(), C.c_uint32()
-        check(lib().sr_host_bvh_get(h, C.byref(np_), C.byref(nn), C.byref(tp), C.byref(nt), C.byref(md)))
-        nodes = np.ctypeslib.as_array(np_, shape=(nn.value, 16)).copy()
+        nn, nt, md, ms = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().sr_host_bvh_get(h, C.byref(np_), C.byref(nn), C.byref(tp), C.byref(nt), C.byref(md), C.byref(ms)))
+        nodes = np.ctypeslib.as_array(np_, shape=(nn.value, 32)).copy()
         tris = np.ctypeslib.as_array(tp, shape=(nt.value, 12)).copy() if nt.value else np.zeros((0, 12), np.float32)
     finally:
         lib().sr_host_bvh_destroy(h)
-    return nodes, tris, md.value
+    return nodes, tris, md.value, ms.value
 
 
 class DeviceFrame:

@@ -90,7 +90,8 @@ def _world_tris(desc):
     return np.concatenate(out).astype(np.float32)
 
 
-def _check_bvh(nodes, tris, max_depth):
+def _check_bvh(nodes, tris, max_depth, max_stack):
+    """4-wide node: lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] child[4] pad[4] (traverse.h)."""
     n = len(tris)
     seen = np.zeros(n, dtype=int)
     depth_seen = [0]
@@ -98,57 +99,58 @@ def _check_bvh(nodes, tris, max_depth):
     def rec(node, depth):
         depth_seen[0] = max(depth_seen[0], depth)
         nd = nodes[node]
-        ch = nd[12:14].view(np.int32)
-        boxes = [(nd[[0, 2, 8]], nd[[1, 3, 9]]), (nd[[4, 6, 10]], nd[[5, 7, 11]])]
+        ch = nd[24:28].view(np.int32)
         lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
-        for c in range(2):
-            lo, hi = boxes[c]
+        stack_below, n_real = 0, 0
+        for c in range(4):
+            lo, hi = nd[[0 + c, 8 + c, 16 + c]], nd[[4 + c, 12 + c, 20 + c]]
             if ch[c] >= 0:
                 assert ch[c] > node  # depth-first order: children follow their parent
-                l2, h2 = rec(int(ch[c]), depth + 1)
+                l2, h2, sb = rec(int(ch[c]), depth + 1)
+                stack_below = max(stack_below, sb)
             else:
                 v = (~int(ch[c])) & 0xFFFFFFFF
                 first, cnt = v >> 3, v & 7
                 assert cnt <= 4
                 if cnt == 0:
+                    assert np.isposinf(lo).all() and np.isneginf(hi).all()  # unused child: nothing can hit it
                     continue
                 tt = tris[first:first + cnt]
                 seen[first:first + cnt] += 1
                 p0 = tt[:, 0:3]
                 allp = np.concatenate([p0, p0 + tt[:, 3:6], p0 + tt[:, 6:9]])
                 l2, h2 = allp.min(0), allp.max(0)
-            assert (lo < l2).all() and (hi > h2).all()  # strictly: boxes are padded by one ulp
+            n_real += 1
+            assert (lo < l2).all() and (hi > h2).all()  # strictly: boxes are padded
             lo_all, hi_all = np.minimum(lo_all, l2), np.maximum(hi_all, h2)
-        return lo_all, hi_all
+        return lo_all, hi_all, stack_below + max(n_real - 1, 0)
 
-    rec(0, 1)
+    _, _, need = rec(0, 1)
     assert (seen == 1).all()
-    assert sorted(tris[:, 11].view(np.uint32)) == list(range(n))
-    assert depth_seen[0] == max_depth <= 32  # never deeper than the kernels' LDS stack (traverse.h)
+    assert sorted(tris[:, 9].view(np.uint32)) == list(range(n))
+    assert depth_seen[0] == max_depth
+    assert need == max_stack <= 24 + 72   # kStackLds + kStackSpill (traverse.h)
 
 
 @pytest.mark.parametrize("scene_fn", [scenes.cornell_box, scenes.cornell_glass_mirror, lambda: scenes.heightfield(n=64, n_lights=3)])
 def test_host_bvh_is_a_valid_tree(scene_fn):
     w = _world_tris(scene_fn())
-    nodes, tris, md = rt.host_bvh(w)
-    _check_bvh(nodes, tris, md)
+    _check_bvh(*rt.host_bvh(w))
 
 
 def test_host_bvh_small_and_degenerate_inputs():
     w = _world_tris(scenes.cornell_box())
     for k in (0, 1, 3, 4, 5, 9):
-        nodes, tris, md = rt.host_bvh(w[:k])
+        nodes, tris, md, ms = rt.host_bvh(w[:k])
         assert len(tris) == k and len(nodes) >= 1  # the root is always an inner node
-        _check_bvh(nodes, tris, md)
+        _check_bvh(nodes, tris, md, ms)
     # 5000 identical triangles: SAH cannot split, the median fallback must keep depth bounded
     same = np.tile(w[:1], (5000, 1))
-    nodes, tris, md = rt.host_bvh(same)
-    _check_bvh(nodes, tris, md)
+    _check_bvh(*rt.host_bvh(same))
     # a long line of tiny triangles: depth guard
     line = np.tile(w[:1], (3000, 1))
     line[:, 0] += np.arange(3000, dtype=np.float32) ** 2
-    nodes, tris, md = rt.host_bvh(line)
-    _check_bvh(nodes, tris, md)
+    _check_bvh(*rt.host_bvh(line))
 
 
 def test_device_entry_points_fail_loudly_without_gpu():
