@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -56,7 +57,7 @@ struct SrScene {
     std::vector<SrMeshInfo> mesh_infos;
     srh::FrameInstanceData fid;
     std::vector<srh::BuildTri> world_tris;
-    DeviceBuffer d_nodes, d_tris, d_shade, d_mesh_const, d_slot_of_gid, d_instances, d_emissive, d_indirection, d_transforms, d_misc;
+    DeviceBuffer d_nodes, d_nodes_q, d_tris, d_shade, d_mesh_const, d_slot_of_gid, d_instances, d_emissive, d_indirection, d_transforms, d_misc;
     srd::DevScene dev{};
     SrBvhStats stats{};
     bool built = false;
@@ -164,7 +165,7 @@ int sr_scene_destroy(SrScene* s) {
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
     for (auto& m : s->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
-    s->d_nodes.release(); s->d_tris.release(); s->d_shade.release(); s->d_mesh_const.release(); s->d_slot_of_gid.release(); s->d_instances.release();
+    s->d_nodes.release(); s->d_nodes_q.release(); s->d_tris.release(); s->d_shade.release(); s->d_mesh_const.release(); s->d_slot_of_gid.release(); s->d_instances.release();
     s->d_emissive.release(); s->d_indirection.release(); s->d_transforms.release(); s->d_misc.release();
     for (auto& pool : s->events) for (auto& e : pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete s;
@@ -228,7 +229,7 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     srh::flatten_instances(s->meshes, s->fid, s->world_tris);
     srh::BvhResult bvh;
     srh::build_bvh(s->world_tris, (uint32_t)srd::kMaxBinaryDepth, bvh);
-    if (bvh.max_stack > (uint32_t)(srd::kStackLds + srd::kStackSpill)) return fail(SR_ERR_STATE, "BVH needs a deeper traversal stack than the kernels provide");
+    if (bvh.max_stack > (uint32_t)srd::kStackMax) return fail(SR_ERR_STATE, "BVH needs a deeper traversal stack than the kernels provide");
     // shade records (object-space vertex normals + instance + mesh slot) in leaf order, slot lookup
     const uint32_t n_tris = s->fid.n_triangles;
     std::vector<float> shade((size_t)n_tris * 12, 0.0f);
@@ -258,6 +259,7 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     memset(dinst.data(), 0, dinst.size() * sizeof(srd::DevInstance));
     for (size_t i = 0; i < s->fid.instances.size(); i++) memcpy(dinst[i].w2o, s->fid.instances[i].w2o, 36);
     if ((rc = s->d_nodes.upload(bvh.nodes.data(), bvh.nodes.size() * 4)) != SR_OK) return rc;
+    if ((rc = s->d_nodes_q.upload(bvh.nodes_q.data(), bvh.nodes_q.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_tris.upload(bvh.tris.data(), bvh.tris.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_shade.upload(shade.data(), shade.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_slot_of_gid.upload(slot_of_gid.data(), slot_of_gid.size() * 4)) != SR_OK) return rc;
@@ -267,6 +269,7 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     if ((rc = s->d_indirection.upload(s->fid.emissive_entries.data(), s->fid.emissive_entries.size() * sizeof(SrEmissiveIndirectionEntry))) != SR_OK) return rc;
     if ((rc = s->d_transforms.upload(s->fid.transforms.data(), s->fid.transforms.size() * sizeof(SrTransform))) != SR_OK) return rc;
     s->dev.nodes = (const float4*)s->d_nodes.p;
+    s->dev.nodes_q = (const float4*)s->d_nodes_q.p;
     s->dev.tris = (const float4*)s->d_tris.p;
     s->dev.shade = (const float4*)s->d_shade.p;
     s->dev.mesh_const = (const srd::DevMeshConst*)s->d_mesh_const.p;
@@ -332,9 +335,10 @@ static int trace_queue(SrScene* s, const SrRay* rays, uint32_t n, SrHit* hits, u
     if (rc != SR_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     uint32_t* queue_head = (uint32_t*)((char*)s->d_misc.p + 32);
-    const int n_blocks = s->n_cus * 5;  // 5 x 32 KB of LDS stack per CU: the residency of this kernel
+    static const int quad = getenv("SR_TRACE_PER_LANE") ? 0 : 1;   // bring-up switch: per-lane vs quad-cooperative tracer
+    const int n_blocks = s->n_cus * 8;
     ScopedTiming tm(s, any ? kAny : kClosest, st);
-    int e = srk_launch_trace(s->dev, rays, n, hits, occluded, queue_head, any, s->instrumented, n_blocks, st);
+    int e = srk_launch_trace(s->dev, rays, n, hits, occluded, queue_head, any, s->instrumented, n_blocks, quad, st);
     if (e != 0) return fail(SR_ERR_HIP, std::string("trace kernel launch: ") + hipGetErrorString((hipError_t)e));
     return SR_OK;
 }

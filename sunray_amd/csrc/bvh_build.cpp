@@ -226,6 +226,7 @@ inline float area_of(const Child4& c) {
 struct Collapser {
     const std::vector<float>& n2;
     std::vector<float>& out;
+    std::vector<float>* out_q = nullptr;
     uint32_t max_depth = 0;
     // returns the worst-case number of stack entries a traversal below (and including) this node needs
     uint32_t emit(int node2, uint32_t depth, int* out_index) {
@@ -244,6 +245,7 @@ struct Collapser {
         const size_t self = out.size();
         *out_index = (int)(self / 32);
         out.resize(self + 32, 0.0f);
+        if (out_q) out_q->resize(self + 32, 0.0f);
         max_depth = std::max(max_depth, depth);
         uint32_t below = 0;
         int n_real = 0;
@@ -265,6 +267,11 @@ struct Collapser {
             float* q = &out[self];
             q[0 + i] = lo[0]; q[4 + i] = hi[0]; q[8 + i] = lo[1]; q[12 + i] = hi[1]; q[16 + i] = lo[2]; q[20 + i] = hi[2];
             memcpy(q + 24 + i, &ref, 4);
+            if (out_q) {   // child-major layout for the quad-cooperative traversal: 32 B per child
+                float* c = &(*out_q)[self + 8 * (size_t)i];
+                c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = hi[0]; c[4] = hi[1]; c[5] = hi[2];
+                memcpy(c + 6, &ref, 4); c[7] = 0.0f;
+            }
         }
         return below + (uint32_t)std::max(n_real - 1, 0);
     }
@@ -273,7 +280,8 @@ struct Collapser {
 
 static void collapse_to_bvh4(BvhResult& res) {
     res.nodes.clear();
-    Collapser c{res.nodes2, res.nodes};
+    res.nodes_q.clear();
+    Collapser c{res.nodes2, res.nodes, &res.nodes_q};
     int root = 0;
     res.max_stack = c.emit(0, 1, &root);
     res.max_depth = c.max_depth;

@@ -22,8 +22,9 @@
 
 namespace srd {
 
-constexpr int kStackLds = 24;        // LDS stack entries per lane (24 KB per 256-thread workgroup)
-constexpr int kStackSpill = 72;      // private overflow; the builder checks max_stack <= kStackLds + kStackSpill
+constexpr int kStackLane = 48;        // LDS stack entries of a per-lane traversal (48 KB per 256 threads)
+constexpr int kStackQuad = 64;        // LDS stack entries of a quad traversal (64 quads x 64 x 4 B = 16 KB per 256 threads)
+constexpr int kStackMax = 48;         // the scene build fails if a traversal could need more than this
 constexpr int kMaxBinaryDepth = 32;  // depth bound of the binary tree the 4-wide tree is collapsed from
 constexpr int kSentinel = 0x7fffffff;
 
@@ -40,6 +41,7 @@ struct DevMeshConst {  // 32 B: the per-mesh constants of the 32-byte RayPayload
 
 struct DevScene {
     const float4* nodes;
+    const float4* nodes_q;
     const float4* tris;
     const float4* shade;
     const DevMeshConst* mesh_const;
@@ -111,28 +113,16 @@ SRD float slab_far(float px, float py, float pz, const RaySetup& r, float t_hi) 
     return fminf(far, t_hi);
 }
 
-struct Stack {
-    int* lds;       // this lane's column: element k at lds[k * stride]
-    int stride;
-    int spill[kStackSpill];
-    int sp;
-    SRD void push(int v) {
-        if (sp < kStackLds) lds[sp * stride] = v;
-        else spill[sp - kStackLds] = v;
-        sp++;
-    }
-    SRD int pop() {
-        if (sp == 0) return kSentinel;
-        sp--;
-        return sp < kStackLds ? lds[sp * stride] : spill[sp - kStackLds];
-    }
-};
+// LDS stack helpers: element k of a column lives at base[k * stride]. The builder bounds the number of
+// entries a traversal of the tree can need (BvhResult::max_stack <= kStackMax), so there is no overflow path.
+#define SR_PUSH(v) do { stack_base[sp * stride] = (v); sp++; } while (0)
+#define SR_POP() (sp == 0 ? kSentinel : stack_base[(--sp) * stride])
 
 SRD int pick(int4 c, uint32_t i) { return i == 0u ? c.x : (i == 1u ? c.y : (i == 2u ? c.z : c.w)); }
 SRD void cswap(uint32_t& a, uint32_t& b) { const uint32_t lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
 
 template <bool ANY, bool STATS>
-SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHit& hit, int* stack_lds, int stride, TravStats& st) {
+SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHit& hit, int* stack_base, int stride, TravStats& st) {
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ tris = sc.tris;
     const RaySetup rs = ray_setup(o, d);
@@ -144,8 +134,7 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
     float cull = fmaf(fabsf(tmax), 1e-5f, tmax);
     float best_t = tmax;
     hit.t = -1.0f; hit.u = 0.0f; hit.v = 0.0f; hit.gid = 0xFFFFFFFFu; hit.slot = 0u;
-    Stack stk;
-    stk.lds = stack_lds; stk.stride = stride; stk.sp = 0;
+    int sp = 0;
     int node = 0;  // the root is always inner node 0
     while (node != kSentinel) {
         while (node >= 0 && node != kSentinel) {
@@ -163,10 +152,10 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
                 int next = kSentinel;
                 bool have = false;
                 if (n0 <= f0) { next = child.x; have = true; }
-                if (n1 <= f1) { if (have) stk.push(child.y); else { next = child.y; have = true; } }
-                if (n2 <= f2) { if (have) stk.push(child.z); else { next = child.z; have = true; } }
-                if (n3 <= f3_) { if (have) stk.push(child.w); else { next = child.w; have = true; } }
-                node = have ? next : stk.pop();
+                if (n1 <= f1) { if (have) SR_PUSH(child.y); else { next = child.y; have = true; } }
+                if (n2 <= f2) { if (have) SR_PUSH(child.z); else { next = child.z; have = true; } }
+                if (n3 <= f3_) { if (have) SR_PUSH(child.w); else { next = child.w; have = true; } }
+                node = have ? next : SR_POP();
             } else {
                 // sort the hit children near-to-far: key = entry distance (clamped to >= 0, low 2 mantissa
                 // bits replaced by the child slot) — positive floats order like unsigned integers
@@ -175,10 +164,10 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
                 uint32_t k2 = (n2 <= f2) ? ((__float_as_uint(fmaxf(n2, 0.0f)) & ~3u) | 2u) : 0xFFFFFFFFu;
                 uint32_t k3 = (n3 <= f3_) ? ((__float_as_uint(fmaxf(n3, 0.0f)) & ~3u) | 3u) : 0xFFFFFFFFu;
                 cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
-                if (k3 != 0xFFFFFFFFu) stk.push(pick(child, k3 & 3u));
-                if (k2 != 0xFFFFFFFFu) stk.push(pick(child, k2 & 3u));
-                if (k1 != 0xFFFFFFFFu) stk.push(pick(child, k1 & 3u));
-                node = (k0 != 0xFFFFFFFFu) ? pick(child, k0 & 3u) : stk.pop();
+                if (k3 != 0xFFFFFFFFu) SR_PUSH(pick(child, k3 & 3u));
+                if (k2 != 0xFFFFFFFFu) SR_PUSH(pick(child, k2 & 3u));
+                if (k1 != 0xFFFFFFFFu) SR_PUSH(pick(child, k1 & 3u));
+                node = (k0 != 0xFFFFFFFFu) ? pick(child, k0 & 3u) : SR_POP();
             }
         }
         if (node == kSentinel) break;
@@ -202,7 +191,7 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
                 }
             }
         }
-        node = stk.pop();
+        node = SR_POP();
     }
     if (STATS) {   // diagnostics: remember the most expensive ray of the launch
         const uint32_t steps = st.boxes - boxes_at_entry;
@@ -214,6 +203,122 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
         }
     }
     return hit.gid != 0xFFFFFFFFu;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quad-cooperative traversal: FOUR lanes (one DPP quad) trace ONE ray.
+//
+// A per-lane traversal makes every lane gather its own 112 bytes per node step: 7 dwordx4 loads x 64
+// different cache lines per wave instruction — the vector L1 / address path, not HBM and not the ALU,
+// bounds it. Here lane q of a quad owns child q of the 4-wide node: the quad reads the
+// 128-byte node as 4 x 32 contiguous bytes (two coalesced dwordx4 per lane, ONE line per quad), each
+// lane runs one slab test, and the quad shares the four results through DPP quad_perm moves — no LDS,
+// no extra latency. Everything that steers the walk (sort, stack, best hit) is computed redundantly
+// and identically by the four lanes, so a quad behaves as one ray; a leaf's <= 4 triangles are tested
+// one per lane. A wave therefore carries 16 rays, and a wave's ACTIVE rays are packed into batches of
+// 16 first — lanes without a ray still help, which removes the idle-lane cost of sparse shadow rays.
+// ---------------------------------------------------------------------------------------------
+SRD uint32_t quad_bcast_u(uint32_t v, int lane_in_quad) {
+    switch (lane_in_quad) {   // compile-time constant at every call site
+        case 0: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, false);
+        case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xF, 0xF, false);
+        case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA, 0xF, 0xF, false);
+        default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF, 0xF, 0xF, false);
+    }
+}
+SRD uint32_t quad_xor1_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }  // [1,0,3,2]
+SRD uint32_t quad_xor2_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); }  // [2,3,0,1]
+SRD float quad_xor1_f(float v) { return __uint_as_float(quad_xor1_u(__float_as_uint(v))); }
+SRD float quad_xor2_f(float v) { return __uint_as_float(quad_xor2_u(__float_as_uint(v))); }
+
+SRD uint32_t pick4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t i) { return i == 0u ? a : (i == 1u ? b : (i == 2u ? c : d)); }
+
+// `valid`, the ray and every output are uniform across the quad. qstack: this QUAD's LDS stack column
+// (element k at qstack[k * stride]); all four lanes store the same value to the same address.
+template <bool ANY, bool STATS>
+SRD bool quad_traverse(const DevScene& sc, bool valid, f3 o, f3 d, float tmin, float tmax, TravHit& hit, int* qstack, int stride, TravStats& st) {
+    const float4* __restrict__ nodes = sc.nodes_q;
+    const float4* __restrict__ tris = sc.tris;
+    const uint32_t q = threadIdx.x & 3u;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const bool sx = (__float_as_uint(inv.x) >> 31) != 0u, sy = (__float_as_uint(inv.y) >> 31) != 0u, sz = (__float_as_uint(inv.z) >> 31) != 0u;
+    const float t_lo = fminf(tmin, 0.0f) - fabsf(tmin);
+    float cull = fmaf(fabsf(tmax), 1e-5f, tmax);
+    float best_t = tmax;
+    hit.t = -1.0f; hit.u = 0.0f; hit.v = 0.0f; hit.gid = 0xFFFFFFFFu; hit.slot = 0u;
+    bool found = false;
+    int* stack_base = qstack;
+    int sp = 0;
+    int node = valid ? 0 : kSentinel;
+    while (node != kSentinel) {
+        while (node >= 0 && node != kSentinel) {
+            const float4* n = nodes + (size_t)node * 8 + q * 2u;
+            const float4 a = n[0];   // lo.x lo.y lo.z hi.x
+            const float4 b = n[1];   // hi.y hi.z ref  pad
+            if (STATS && q == 0u) st.boxes += 4;
+            const float tnx = ((sx ? a.w : a.x) - o.x) * inv.x, tfx = ((sx ? a.x : a.w) - o.x) * inv.x;
+            const float tny = ((sy ? b.x : a.y) - o.y) * inv.y, tfy = ((sy ? a.y : b.x) - o.y) * inv.y;
+            const float tnz = ((sz ? b.y : a.z) - o.z) * inv.z, tfz = ((sz ? a.z : b.y) - o.z) * inv.z;
+            const float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, t_lo));
+            float far = fminf(fminf(tfx, tfy), tfz);
+            far = far * (1.0f + copysignf(5e-7f, far));
+            const bool h = t0 <= fminf(far, cull);
+            const uint32_t key = h ? ((__float_as_uint(fmaxf(t0, 0.0f)) & ~3u) | q) : 0xFFFFFFFFu;
+            const uint32_t ref = __float_as_uint(b.z);
+            uint32_t k0 = quad_bcast_u(key, 0), k1 = quad_bcast_u(key, 1), k2 = quad_bcast_u(key, 2), k3 = quad_bcast_u(key, 3);
+            const uint32_t r0 = quad_bcast_u(ref, 0), r1 = quad_bcast_u(ref, 1), r2 = quad_bcast_u(ref, 2), r3 = quad_bcast_u(ref, 3);
+            if (!ANY) { cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2); }
+            else {   // order is irrelevant for an existence query: just move the hits to the front
+                cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
+            }
+            if (k3 != 0xFFFFFFFFu) SR_PUSH((int)pick4(r0, r1, r2, r3, k3 & 3u));
+            if (k2 != 0xFFFFFFFFu) SR_PUSH((int)pick4(r0, r1, r2, r3, k2 & 3u));
+            if (k1 != 0xFFFFFFFFu) SR_PUSH((int)pick4(r0, r1, r2, r3, k1 & 3u));
+            node = (k0 != 0xFFFFFFFFu) ? (int)pick4(r0, r1, r2, r3, k0 & 3u) : SR_POP();
+        }
+        if (node == kSentinel) break;
+        // leaf: lane q tests triangle q
+        const uint32_t lv = ~(uint32_t)node;
+        const uint32_t first = lv >> 3, cnt = lv & 7u;
+        float t = 0.0f, u = 0.0f, v = 0.0f;
+        uint32_t gid = 0xFFFFFFFFu;
+        bool th = false;
+        if (q < cnt) {
+            const float4 t0 = tris[(size_t)(first + q) * 3 + 0];
+            const float4 t1 = tris[(size_t)(first + q) * 3 + 1];
+            const float4 t2 = tris[(size_t)(first + q) * 3 + 2];
+            if (STATS) st.tris += 1;
+            th = intersect_tri(o, d, mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), tmin, tmax, t, u, v);
+            gid = __float_as_uint(t2.y);
+        }
+        // reduce over the quad: smallest t, ties to the lowest global triangle index
+        float bt = th ? t : __builtin_inff();
+        uint32_t bg = th ? gid : 0xFFFFFFFFu;
+        float bu = u, bv = v;
+        uint32_t bslot = first + q;
+        {
+            const float ot = quad_xor1_f(bt); const uint32_t og = quad_xor1_u(bg);
+            const float ou = quad_xor1_f(bu), ov = quad_xor1_f(bv); const uint32_t os = quad_xor1_u(bslot);
+            const bool take = (ot < bt) || (ot == bt && og < bg);
+            bt = take ? ot : bt; bg = take ? og : bg; bu = take ? ou : bu; bv = take ? ov : bv; bslot = take ? os : bslot;
+        }
+        {
+            const float ot = quad_xor2_f(bt); const uint32_t og = quad_xor2_u(bg);
+            const float ou = quad_xor2_f(bu), ov = quad_xor2_f(bv); const uint32_t os = quad_xor2_u(bslot);
+            const bool take = (ot < bt) || (ot == bt && og < bg);
+            bt = take ? ot : bt; bg = take ? og : bg; bu = take ? ou : bu; bv = take ? ov : bv; bslot = take ? os : bslot;
+        }
+        if (bg != 0xFFFFFFFFu) {
+            if (ANY) { found = true; break; }
+            if (bt < best_t || (bt == best_t && bg < hit.gid)) {
+                best_t = bt;
+                hit.t = bt; hit.u = bu; hit.v = bv; hit.gid = bg; hit.slot = bslot;
+                cull = fmaf(fabsf(bt), 1e-5f, bt);
+            }
+        }
+        node = SR_POP();
+    }
+    return ANY ? found : (hit.gid != 0xFFFFFFFFu);
 }
 
 // Payload of one closest-hit query in registers (rt_types.slang:9-16).

@@ -129,7 +129,7 @@ def _check_bvh(nodes, tris, max_depth, max_stack):
     assert (seen == 1).all()
     assert sorted(tris[:, 9].view(np.uint32)) == list(range(n))
     assert depth_seen[0] == max_depth
-    assert need == max_stack <= 24 + 72   # kStackLds + kStackSpill (traverse.h)
+    assert need == max_stack <= 48   # kStackMax (traverse.h)
 
 
 @pytest.mark.parametrize("scene_fn", [scenes.cornell_box, scenes.cornell_glass_mirror, lambda: scenes.heightfield(n=64, n_lights=3)])
