@@ -304,7 +304,7 @@ int sr_scene_get_tables(const SrScene* scene, const SrTransform** transforms, ui
 /* BVH statistics for roofline accounting. */
 typedef struct SrBvhStats {
     uint64_t n_triangles;
-    uint64_t n_nodes;     /* 4-wide nodes, 128 B each (four 32-B child boxes) */
+    uint64_t n_nodes;     /* 4-wide nodes with quantised child boxes, 64 B each */
     uint64_t node_bytes;
     uint64_t tri_bytes;   /* 48 B per triangle record */
     uint32_t max_depth;   /* of the 4-wide tree */
@@ -319,12 +319,12 @@ int sr_scene_resolve_triangle(const SrScene* scene, uint32_t tri, uint32_t* inst
 
 /* Host-only access to the BVH builder (no GPU needed): builds the same BVH sr_scene_set_instances
  * would build over n world-space triangles given as 9 floats each (v0, e1, e2), for structural
- * checks on machines without a device. nodes: 32 floats per 4-wide node, tris: 12 floats per
- * triangle in leaf order (layout: sunray_amd/csrc/traverse.h). max_stack: worst-case traversal
+ * checks on machines without a device. nodes: 16 dwords per 4-wide quantised node, tris: 12 floats
+ * per triangle in leaf order (layout: sunray_amd/csrc/traverse.h). max_stack: worst-case traversal
  * stack entries. */
 typedef struct SrHostBvh SrHostBvh;
 int sr_host_bvh_build(const float* v0_e1_e2, uint32_t n_triangles, SrHostBvh** out);
-int sr_host_bvh_get(const SrHostBvh* bvh, const float** nodes, uint32_t* n_nodes, const float** tris,
+int sr_host_bvh_get(const SrHostBvh* bvh, const uint32_t** nodes, uint32_t* n_nodes, const float** tris,
                     uint32_t* n_triangles, uint32_t* max_depth, uint32_t* max_stack);
 int sr_host_bvh_destroy(SrHostBvh* bvh);
 

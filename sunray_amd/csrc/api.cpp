@@ -3,6 +3,7 @@
 // the host-side data preparation (host_prep.cpp, bvh_build.cpp) and the HIP kernels (kernels.hip).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -57,13 +58,14 @@ struct SrScene {
     std::vector<SrMeshInfo> mesh_infos;
     srh::FrameInstanceData fid;
     std::vector<srh::BuildTri> world_tris;
-    DeviceBuffer d_nodes, d_nodes_q, d_tris, d_shade, d_mesh_const, d_slot_of_gid, d_instances, d_emissive, d_indirection, d_transforms, d_misc;
+    DeviceBuffer d_nodes, d_tris, d_shade, d_mesh_const, d_slot_of_gid, d_instances, d_emissive, d_indirection, d_transforms, d_misc;
     srd::DevScene dev{};
     SrBvhStats stats{};
     bool built = false;
     int instrumented = 0;
     int timing = 0;
     int n_cus = 256;
+    int stack_entries = 8;   // LDS traversal-stack entries per lane this scene's tree needs (multiple of 4)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events[kNumKinds];
     size_t events_used[kNumKinds] = {0, 0, 0, 0};
 };
@@ -165,7 +167,7 @@ int sr_scene_destroy(SrScene* s) {
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
     for (auto& m : s->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
-    s->d_nodes.release(); s->d_nodes_q.release(); s->d_tris.release(); s->d_shade.release(); s->d_mesh_const.release(); s->d_slot_of_gid.release(); s->d_instances.release();
+    s->d_nodes.release(); s->d_tris.release(); s->d_shade.release(); s->d_mesh_const.release(); s->d_slot_of_gid.release(); s->d_instances.release();
     s->d_emissive.release(); s->d_indirection.release(); s->d_transforms.release(); s->d_misc.release();
     for (auto& pool : s->events) for (auto& e : pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete s;
@@ -259,7 +261,6 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     memset(dinst.data(), 0, dinst.size() * sizeof(srd::DevInstance));
     for (size_t i = 0; i < s->fid.instances.size(); i++) memcpy(dinst[i].w2o, s->fid.instances[i].w2o, 36);
     if ((rc = s->d_nodes.upload(bvh.nodes.data(), bvh.nodes.size() * 4)) != SR_OK) return rc;
-    if ((rc = s->d_nodes_q.upload(bvh.nodes_q.data(), bvh.nodes_q.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_tris.upload(bvh.tris.data(), bvh.tris.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_shade.upload(shade.data(), shade.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_slot_of_gid.upload(slot_of_gid.data(), slot_of_gid.size() * 4)) != SR_OK) return rc;
@@ -269,7 +270,6 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     if ((rc = s->d_indirection.upload(s->fid.emissive_entries.data(), s->fid.emissive_entries.size() * sizeof(SrEmissiveIndirectionEntry))) != SR_OK) return rc;
     if ((rc = s->d_transforms.upload(s->fid.transforms.data(), s->fid.transforms.size() * sizeof(SrTransform))) != SR_OK) return rc;
     s->dev.nodes = (const float4*)s->d_nodes.p;
-    s->dev.nodes_q = (const float4*)s->d_nodes_q.p;
     s->dev.tris = (const float4*)s->d_tris.p;
     s->dev.shade = (const float4*)s->d_shade.p;
     s->dev.mesh_const = (const srd::DevMeshConst*)s->d_mesh_const.p;
@@ -284,9 +284,10 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     s->dev.n_instances = (uint32_t)s->fid.instances.size();
     s->stats.n_triangles = s->fid.n_triangles;
     s->stats.n_nodes = bvh.n_nodes;
-    s->stats.node_bytes = (uint64_t)bvh.n_nodes * 128;
+    s->stats.node_bytes = (uint64_t)bvh.n_nodes * 64;
     s->stats.tri_bytes = (uint64_t)s->fid.n_triangles * 48;
     s->stats.max_depth = bvh.max_depth;
+    s->stack_entries = (int)((std::max(bvh.max_stack, 4u) + 3u) & ~3u);
     s->stats.sah_cost = bvh.sah_cost;
     s->stats.build_ms = bvh.build_ms;
     s->built = true;
@@ -335,10 +336,12 @@ static int trace_queue(SrScene* s, const SrRay* rays, uint32_t n, SrHit* hits, u
     if (rc != SR_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     uint32_t* queue_head = (uint32_t*)((char*)s->d_misc.p + 32);
-    static const int quad = getenv("SR_TRACE_PER_LANE") ? 0 : 1;   // bring-up switch: per-lane vs quad-cooperative tracer
-    const int n_blocks = s->n_cus * 8;
+    const int lds_per_block = s->stack_entries * 256 * 4;
+    int per_cu = std::max(1, std::min(8, 160 * 1024 / lds_per_block));  // persistent grid = LDS-limited residency
+    if (const char* e = getenv("SR_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));   // tuning switch
+    const int n_blocks = s->n_cus * per_cu;
     ScopedTiming tm(s, any ? kAny : kClosest, st);
-    int e = srk_launch_trace(s->dev, rays, n, hits, occluded, queue_head, any, s->instrumented, n_blocks, quad, st);
+    int e = srk_launch_trace(s->dev, rays, n, hits, occluded, queue_head, any, s->instrumented, n_blocks, s->stack_entries, st);
     if (e != 0) return fail(SR_ERR_HIP, std::string("trace kernel launch: ") + hipGetErrorString((hipError_t)e));
     return SR_OK;
 }
@@ -407,7 +410,7 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
     a.cfg = p->config;
     hipStream_t st = (hipStream_t)stream;
     ScopedTiming tm(s, which == 0 ? kRis : kFinal, st);
-    int e = srk_launch_pass(a, which, s->instrumented, st);
+    int e = srk_launch_pass(a, which, s->instrumented, s->stack_entries, st);
     if (e != 0) return fail(SR_ERR_HIP, std::string(name) + " launch: " + hipGetErrorString((hipError_t)e));
     return SR_OK;
 }
@@ -495,7 +498,7 @@ int sr_host_bvh_build(const float* v, uint32_t n, SrHostBvh** out) {
     *out = reinterpret_cast<SrHostBvh*>(h);
     return SR_OK;
 }
-int sr_host_bvh_get(const SrHostBvh* bvh, const float** nodes, uint32_t* n_nodes, const float** tris, uint32_t* n_triangles, uint32_t* max_depth, uint32_t* max_stack) {
+int sr_host_bvh_get(const SrHostBvh* bvh, const uint32_t** nodes, uint32_t* n_nodes, const float** tris, uint32_t* n_triangles, uint32_t* max_depth, uint32_t* max_stack) {
     if (!bvh) return fail(SR_ERR_INVALID_ARG, "sr_host_bvh_get: null handle");
     const auto* h = reinterpret_cast<const SrHostBvhImpl*>(bvh);
     if (nodes) *nodes = h->r.nodes.data();

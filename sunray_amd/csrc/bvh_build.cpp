@@ -203,12 +203,17 @@ struct Builder {
 
 }  // namespace
 
-// Collapse the binary tree into a 4-wide tree: a node adopts its two children, then repeatedly
-// replaces the inner child with the largest surface area by that child's two children until it has
-// four (or only leaves are left). One 128-byte node per step halves the number of dependent memory
-// round trips of a traversal, which is what bounds the kernels.
-// Node layout (32 floats): lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] child[4] pad[4];
-// unused children have an empty box (lo = +inf, hi = -inf) and an empty-leaf reference.
+// Collapse the binary tree into a 4-wide tree with QUANTISED child boxes: a node adopts its two
+// children, then repeatedly replaces the inner child with the largest surface area by that child's two
+// children until it has four (or only leaves are left). Traversal is bound by vector-L1 tag lookups
+// (one per 16-byte gather per lane), so a node is packed into 64 bytes = 4 gathers per step:
+//   [0]  origin.x origin.y origin.z | exponents ex | ey<<8 | ez<<16   (the node's own lower corner, per-axis 2^e grid)
+//   [16] LX LY LZ HX   one dword per plane set: byte c = child c's plane, in grid steps from the origin
+//   [32] HY HZ - -
+//   [48] child[4]      >= 0: node index; < 0: leaf, ~child = (first_triangle << 3) | count
+// Decoding (device): plane = fmaf(q, 2^e, origin). Quantisation rounds lower planes down and upper
+// planes up and is verified here with the SAME fmaf, so a decoded box always contains the exact one.
+// Unused children decode to an inverted box (lo byte 255, hi byte 0) and carry an empty-leaf reference.
 namespace {
 struct Child4 { float lo[3], hi[3]; int ref; };
 inline Child4 child_of(const float* n2, int which) {
@@ -225,8 +230,7 @@ inline float area_of(const Child4& c) {
 }
 struct Collapser {
     const std::vector<float>& n2;
-    std::vector<float>& out;
-    std::vector<float>* out_q = nullptr;
+    std::vector<uint32_t>& out;   // 16 dwords per node
     uint32_t max_depth = 0;
     // returns the worst-case number of stack entries a traversal below (and including) this node needs
     uint32_t emit(int node2, uint32_t depth, int* out_index) {
@@ -242,37 +246,79 @@ struct Collapser {
             kids[best] = child_of(&n2[(size_t)inner * 16], 0);
             kids[nk++] = child_of(&n2[(size_t)inner * 16], 1);
         }
-        const size_t self = out.size();
-        *out_index = (int)(self / 32);
-        out.resize(self + 32, 0.0f);
-        if (out_q) out_q->resize(self + 32, 0.0f);
-        max_depth = std::max(max_depth, depth);
-        uint32_t below = 0;
+        bool real[4] = {false, false, false, false};
         int n_real = 0;
-        for (int i = 0; i < 4; i++) {
-            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-            int ref = Builder::leaf_ref(0, 0);
-            if (i < nk) {
-                const bool empty_leaf = kids[i].ref < 0 && ((~(uint32_t)kids[i].ref) & 7u) == 0u;
-                if (!empty_leaf) {
-                    n_real++;
-                    memcpy(lo, kids[i].lo, 12); memcpy(hi, kids[i].hi, 12);
-                    if (kids[i].ref >= 0) {
-                        int idx = 0;
-                        below = std::max(below, emit(kids[i].ref, depth + 1, &idx));
-                        ref = idx;
-                    } else ref = kids[i].ref;
+        float lo_n[3] = {INFINITY, INFINITY, INFINITY}, hi_n[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = 0; i < nk; i++) {
+            const bool empty_leaf = kids[i].ref < 0 && ((~(uint32_t)kids[i].ref) & 7u) == 0u;
+            real[i] = !empty_leaf;
+            if (!real[i]) continue;
+            n_real++;
+            for (int a = 0; a < 3; a++) { lo_n[a] = std::min(lo_n[a], kids[i].lo[a]); hi_n[a] = std::max(hi_n[a], kids[i].hi[a]); }
+        }
+        const size_t self = out.size();
+        *out_index = (int)(self / 16);
+        out.resize(self + 16, 0u);
+        max_depth = std::max(max_depth, depth);
+        uint32_t plane[6] = {0, 0, 0, 0, 0, 0};   // LX LY LZ HX HY HZ
+        uint32_t exps = 0;
+        float origin[3] = {0.0f, 0.0f, 0.0f};
+        if (n_real > 0) {
+            for (int a = 0; a < 3; a++) {
+                origin[a] = lo_n[a];
+                const float ext = hi_n[a] - lo_n[a];
+                int e = -126;
+                if (ext > 0.0f) { int fe; (void)std::frexp(ext / 255.0f, &fe); e = std::max(fe, -126); }   // 2^fe >= ext/255
+                for (;;) {   // grow the grid until every child's upper plane fits in a byte
+                    const float scale = std::ldexp(1.0f, e);
+                    bool ok = true;
+                    for (int i = 0; i < nk && ok; i++) {
+                        if (!real[i]) continue;
+                        int qh = (int)std::ceil(((double)kids[i].hi[a] - (double)origin[a]) / (double)scale);
+                        qh = std::max(qh, 0);
+                        while (qh <= 255 && fmaf((float)qh, scale, origin[a]) < kids[i].hi[a]) qh++;
+                        if (qh > 255) ok = false;
+                    }
+                    if (ok) break;
+                    e++;
+                }
+                const float scale = std::ldexp(1.0f, e);
+                exps |= (uint32_t)(e + 127) << (8 * a);
+                for (int i = 0; i < 4; i++) {
+                    uint32_t ql = 255u, qh = 0u;   // inverted box for unused children
+                    if (i < nk && real[i]) {
+                        int l = (int)std::floor(((double)kids[i].lo[a] - (double)origin[a]) / (double)scale);
+                        l = std::min(std::max(l, 0), 255);
+                        while (l > 0 && fmaf((float)l, scale, origin[a]) > kids[i].lo[a]) l--;
+                        int h = (int)std::ceil(((double)kids[i].hi[a] - (double)origin[a]) / (double)scale);
+                        h = std::max(h, 0);
+                        while (fmaf((float)h, scale, origin[a]) < kids[i].hi[a]) h++;
+                        ql = (uint32_t)l; qh = (uint32_t)h;
+                    }
+                    plane[a] |= ql << (8 * i);
+                    plane[3 + a] |= qh << (8 * i);
                 }
             }
-            float* q = &out[self];
-            q[0 + i] = lo[0]; q[4 + i] = hi[0]; q[8 + i] = lo[1]; q[12 + i] = hi[1]; q[16 + i] = lo[2]; q[20 + i] = hi[2];
-            memcpy(q + 24 + i, &ref, 4);
-            if (out_q) {   // child-major layout for the quad-cooperative traversal: 32 B per child
-                float* c = &(*out_q)[self + 8 * (size_t)i];
-                c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = hi[0]; c[4] = hi[1]; c[5] = hi[2];
-                memcpy(c + 6, &ref, 4); c[7] = 0.0f;
+        } else {
+            for (int a = 0; a < 3; a++) { plane[a] = 0xFFFFFFFFu; plane[3 + a] = 0u; exps |= 127u << (8 * a); }
+        }
+        uint32_t below = 0;
+        int refs[4];
+        for (int i = 0; i < 4; i++) {
+            refs[i] = Builder::leaf_ref(0, 0);
+            if (i < nk && real[i]) {
+                if (kids[i].ref >= 0) {
+                    int idx = 0;
+                    below = std::max(below, emit(kids[i].ref, depth + 1, &idx));
+                    refs[i] = idx;
+                } else refs[i] = kids[i].ref;
             }
         }
+        uint32_t* q = &out[self];
+        memcpy(q + 0, origin, 12); q[3] = exps;
+        q[4] = plane[0]; q[5] = plane[1]; q[6] = plane[2]; q[7] = plane[3];
+        q[8] = plane[4]; q[9] = plane[5]; q[10] = 0u; q[11] = 0u;
+        memcpy(q + 12, refs, 16);
         return below + (uint32_t)std::max(n_real - 1, 0);
     }
 };
@@ -280,12 +326,11 @@ struct Collapser {
 
 static void collapse_to_bvh4(BvhResult& res) {
     res.nodes.clear();
-    res.nodes_q.clear();
-    Collapser c{res.nodes2, res.nodes, &res.nodes_q};
+    Collapser c{res.nodes2, res.nodes};
     int root = 0;
     res.max_stack = c.emit(0, 1, &root);
     res.max_depth = c.max_depth;
-    res.n_nodes = (uint32_t)(res.nodes.size() / 32);
+    res.n_nodes = (uint32_t)(res.nodes.size() / 16);
 }
 
 void flatten_instances(const std::vector<HostMesh>& meshes, const FrameInstanceData& fid, std::vector<BuildTri>& out) {

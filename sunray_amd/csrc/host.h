@@ -64,8 +64,7 @@ struct BuildTri {
 };
 struct BvhResult {
     std::vector<float> nodes2; // intermediate binary tree: 16 floats per inner node (two child boxes)
-    std::vector<float> nodes;  // the 4-wide tree the kernels traverse: 32 floats (128 B) per node
-    std::vector<float> nodes_q; // same tree, child-major: child i = (lo.xyz, hi.xyz, ref, pad) at floats [8i, 8i+8)
+    std::vector<uint32_t> nodes;  // the 4-wide quantised tree the kernels traverse: 16 dwords (64 B) per node
     std::vector<float> tris;   // 12 floats (48 B) per triangle, leaf order
     std::vector<uint32_t> order;  // leaf slot -> index into the input triangle list
     uint32_t n_nodes = 0, max_depth = 0, max_stack = 0;

@@ -30,7 +30,7 @@ template <bool ANY, bool STATS>
 __global__ __launch_bounds__(kBlock) void trace_queue_kernel(DevScene sc, const SrRay* __restrict__ rays, uint32_t n,
                                                              SrHit* __restrict__ hits, uint32_t* __restrict__ occluded,
                                                              uint32_t* __restrict__ queue_head) {
-    __shared__ int s_stack[kStackLane * kBlock];
+    extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kBlock], sized at launch
     const int lane = threadIdx.x & 63;
     int* stack = s_stack + threadIdx.x;
     uint32_t n_queries = 0;
@@ -53,51 +53,6 @@ __global__ __launch_bounds__(kBlock) void trace_queue_kernel(DevScene sc, const 
                 o.x = h.t; o.y = h.u; o.z = h.v; o.w = __uint_as_float(h.gid);
                 reinterpret_cast<float4*>(hits)[i] = o;
             }
-        }
-    }
-    flush_counter(sc.counters + (ANY ? 1 : 0), n_queries);
-    if (STATS) { flush_counter(sc.counters + 2, st.boxes); flush_counter(sc.counters + 3, st.tris); }
-}
-
-// Quad-cooperative variant: a wave pulls 64 rays, then traces them as 4 batches of 16 rays x 4 lanes.
-template <bool ANY, bool STATS>
-__global__ __launch_bounds__(kBlock) void trace_queue_quad_kernel(DevScene sc, const SrRay* __restrict__ rays, uint32_t n,
-                                                                  SrHit* __restrict__ hits, uint32_t* __restrict__ occluded,
-                                                                  uint32_t* __restrict__ queue_head) {
-    __shared__ int s_stack[kStackQuad * (kBlock / 4)];
-    const int lane = threadIdx.x & 63;
-    int* qstack = s_stack + (threadIdx.x >> 2);
-    uint32_t n_queries = 0;
-    TravStats st; st.boxes = 0; st.tris = 0;
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(queue_head, 64u);
-        base = __shfl(base, 0);
-        if (base >= n) break;
-        const uint32_t i = base + lane;
-        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 1.f, 0.f);
-        if (i < n) { ra = reinterpret_cast<const float4*>(rays)[i * 2 + 0]; rb = reinterpret_cast<const float4*>(rays)[i * 2 + 1]; n_queries++; }
-        float4 res = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-        uint32_t occ = 0u;
-        for (int b = 0; b < 4; b++) {
-            const int src = 16 * b + (lane >> 2);
-            const f3 o = mk3(__shfl(ra.x, src), __shfl(ra.y, src), __shfl(ra.z, src));
-            const float tmin = __shfl(ra.w, src);
-            const f3 d = mk3(__shfl(rb.x, src), __shfl(rb.y, src), __shfl(rb.z, src));
-            const float tmax = __shfl(rb.w, src);
-            const bool valid = (base + (uint32_t)src) < n;
-            TravHit h;
-            const bool found = quad_traverse<ANY, STATS>(sc, valid, o, d, tmin, tmax, h, qstack, kBlock / 4, st);
-            // route the quad's result back to the lane that owns the ray
-            const int from = 4 * (lane & 15);
-            const float rt = __shfl(h.t, from), ru = __shfl(h.u, from), rv = __shfl(h.v, from);
-            const uint32_t rg = __shfl(h.gid, from);
-            const uint32_t rf = __shfl(found ? 1u : 0u, from);
-            if ((lane >> 4) == b) { res.x = rt; res.y = ru; res.z = rv; res.w = __uint_as_float(rg); occ = rf; }
-        }
-        if (i < n) {
-            if (ANY) occluded[i] = occ;
-            else reinterpret_cast<float4*>(hits)[i] = res;
         }
     }
     flush_counter(sc.counters + (ANY ? 1 : 0), n_queries);
@@ -242,7 +197,7 @@ SRD bool thread_pixel(const PassArgs& a, uint32_t& px, uint32_t& py) {
 
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
-    __shared__ int s_stack[kStackLane * kBlock];
+    extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kBlock], sized at launch
     PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
     const DevScene& sc = a.sc;
     uint32_t px = 0, py = 0;
@@ -484,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
 
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
-    __shared__ int s_stack[kStackLane * kBlock];
+    extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kBlock], sized at launch
     PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
     const DevScene& sc = a.sc;
     uint32_t px = 0, py = 0;
@@ -758,27 +713,18 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
 using namespace srd;
 
 int srk_launch_trace(const DevScene& sc, const SrRay* rays, uint32_t n, SrHit* hits, uint32_t* occluded,
-                     uint32_t* queue_head, int any, int stats, int n_blocks, int quad, hipStream_t stream) {
+                     uint32_t* queue_head, int any, int stats, int n_blocks, int stack_entries, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(queue_head, 0, 16, stream);
     if (e != hipSuccess) return (int)e;
     if (n == 0) return 0;
     dim3 grid(n_blocks), block(kBlock);
-    if (quad) {
-        if (any) {
-            if (stats) trace_queue_quad_kernel<true, true><<<grid, block, 0, stream>>>(sc, rays, n, hits, occluded, queue_head);
-            else trace_queue_quad_kernel<true, false><<<grid, block, 0, stream>>>(sc, rays, n, hits, occluded, queue_head);
-        } else {
-            if (stats) trace_queue_quad_kernel<false, true><<<grid, block, 0, stream>>>(sc, rays, n, hits, occluded, queue_head);
-            else trace_queue_quad_kernel<false, false><<<grid, block, 0, stream>>>(sc, rays, n, hits, occluded, queue_head);
-        }
-        return (int)hipGetLastError();
-    }
+    const size_t lds = (size_t)stack_entries * kBlock * sizeof(int);
     if (any) {
-        if (stats) trace_queue_kernel<true, true><<<grid, block, 0, stream>>>(sc, rays, n, hits, occluded, queue_head);
-        else trace_queue_kernel<true, false><<<grid, block, 0, stream>>>(sc, rays, n, hits, occluded, queue_head);
+        if (stats) trace_queue_kernel<true, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head);
+        else trace_queue_kernel<true, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head);
     } else {
-        if (stats) trace_queue_kernel<false, true><<<grid, block, 0, stream>>>(sc, rays, n, hits, occluded, queue_head);
-        else trace_queue_kernel<false, false><<<grid, block, 0, stream>>>(sc, rays, n, hits, occluded, queue_head);
+        if (stats) trace_queue_kernel<false, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head);
+        else trace_queue_kernel<false, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head);
     }
     return (int)hipGetLastError();
 }
@@ -789,16 +735,17 @@ int srk_launch_shade(const DevScene& sc, const SrHit* hits, uint32_t n, SrRayPay
     return (int)hipGetLastError();
 }
 
-int srk_launch_pass(const PassArgs& args, int which, int stats, hipStream_t stream) {
+int srk_launch_pass(const PassArgs& args, int which, int stats, int stack_entries, hipStream_t stream) {
     const uint32_t n_tiles = args.tiles_x * args.tiles_y;
     if (n_tiles == 0) return 0;
     dim3 grid(args.tiles_per_xcd * 8), block(kBlock);
+    const size_t lds = (size_t)stack_entries * kBlock * sizeof(int);
     if (which == 0) {
-        if (stats) ris_kernel<true><<<grid, block, 0, stream>>>(args);
-        else ris_kernel<false><<<grid, block, 0, stream>>>(args);
+        if (stats) ris_kernel<true><<<grid, block, lds, stream>>>(args);
+        else ris_kernel<false><<<grid, block, lds, stream>>>(args);
     } else {
-        if (stats) final_kernel<true><<<grid, block, 0, stream>>>(args);
-        else final_kernel<false><<<grid, block, 0, stream>>>(args);
+        if (stats) final_kernel<true><<<grid, block, lds, stream>>>(args);
+        else final_kernel<false><<<grid, block, lds, stream>>>(args);
     }
     return (int)hipGetLastError();
 }

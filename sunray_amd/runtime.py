@@ -48,19 +48,39 @@ def emissive_triangles_from_mesh(vertices, indices, material):
 
 
 def host_bvh(v0_e1_e2):
-    """Host-only BVH build (no GPU): returns (nodes[n,32] f32, tris[n,12] f32, max_depth, max_stack)."""
+    """Host-only BVH build (no GPU): returns (nodes[n,16] u32, tris[n,12] f32, max_depth, max_stack)."""
     v = np.ascontiguousarray(v0_e1_e2, dtype=np.float32).reshape(-1, 9)
     h = C.c_void_p()
     check(lib().sr_host_bvh_build(_p(v), C.c_uint32(len(v)), C.byref(h)))
     try:
-        np_, tp = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+        np_, tp = C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()
         nn, nt, md, ms = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(lib().sr_host_bvh_get(h, C.byref(np_), C.byref(nn), C.byref(tp), C.byref(nt), C.byref(md), C.byref(ms)))
-        nodes = np.ctypeslib.as_array(np_, shape=(nn.value, 32)).copy()
+        nodes = np.ctypeslib.as_array(np_, shape=(nn.value, 16)).copy()
         tris = np.ctypeslib.as_array(tp, shape=(nt.value, 12)).copy() if nt.value else np.zeros((0, 12), np.float32)
     finally:
         lib().sr_host_bvh_destroy(h)
     return nodes, tris, md.value, ms.value
+
+
+def decode_node(node16):
+    """Child boxes of one 64-byte quantised node as the kernel decodes them: plane = fmaf(q, 2^e, origin).
+    Returns (lo[4,3], hi[4,3], child[4]) in float32 / int32."""
+    n = np.asarray(node16, dtype=np.uint32)
+    origin = n[0:3].view(np.float32)
+    ex = int(n[3])
+    scale = np.array([np.uint32(((ex >> (8 * a)) & 0xFF) << 23) for a in range(3)], dtype=np.uint32).view(np.float32)
+    planes = n[4:10]  # LX LY LZ HX HY HZ
+    lo = np.zeros((4, 3), np.float32)
+    hi = np.zeros((4, 3), np.float32)
+    for c in range(4):
+        for a in range(3):
+            ql = np.float32((int(planes[a]) >> (8 * c)) & 0xFF)
+            qh = np.float32((int(planes[3 + a]) >> (8 * c)) & 0xFF)
+            # one rounding, like v_fma_f32: the product q * 2^e is exact in float64
+            lo[c, a] = np.float32(np.float64(ql) * np.float64(scale[a]) + np.float64(origin[a]))
+            hi[c, a] = np.float32(np.float64(qh) * np.float64(scale[a]) + np.float64(origin[a]))
+    return lo, hi, n[12:16].view(np.int32)
 
 
 class DeviceFrame:

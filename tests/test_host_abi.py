@@ -91,19 +91,19 @@ def _world_tris(desc):
 
 
 def _check_bvh(nodes, tris, max_depth, max_stack):
-    """4-wide node: lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] child[4] pad[4] (traverse.h)."""
+    """Walks the 64-byte quantised 4-wide nodes exactly as the kernel decodes them (traverse.h)."""
     n = len(tris)
     seen = np.zeros(n, dtype=int)
     depth_seen = [0]
+    slack = [0.0]
 
     def rec(node, depth):
         depth_seen[0] = max(depth_seen[0], depth)
-        nd = nodes[node]
-        ch = nd[24:28].view(np.int32)
+        lo4, hi4, ch = rt.decode_node(nodes[node])
         lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
         stack_below, n_real = 0, 0
         for c in range(4):
-            lo, hi = nd[[0 + c, 8 + c, 16 + c]], nd[[4 + c, 12 + c, 20 + c]]
+            lo, hi = lo4[c], hi4[c]
             if ch[c] >= 0:
                 assert ch[c] > node  # depth-first order: children follow their parent
                 l2, h2, sb = rec(int(ch[c]), depth + 1)
@@ -113,7 +113,7 @@ def _check_bvh(nodes, tris, max_depth, max_stack):
                 first, cnt = v >> 3, v & 7
                 assert cnt <= 4
                 if cnt == 0:
-                    assert np.isposinf(lo).all() and np.isneginf(hi).all()  # unused child: nothing can hit it
+                    assert (lo > hi).all()  # unused child decodes to an inverted box
                     continue
                 tt = tris[first:first + cnt]
                 seen[first:first + cnt] += 1
@@ -121,15 +121,23 @@ def _check_bvh(nodes, tris, max_depth, max_stack):
                 allp = np.concatenate([p0, p0 + tt[:, 3:6], p0 + tt[:, 6:9]])
                 l2, h2 = allp.min(0), allp.max(0)
             n_real += 1
-            assert (lo < l2).all() and (hi > h2).all()  # strictly: boxes are padded
+            # every decoded box strictly contains the GEOMETRY below it (a descendant's decoded box may
+            # stick out of an ancestor's: each level rounds outward on its own grid)
+            assert (lo < l2).all() and (hi > h2).all()
+            ext = np.maximum(hi4[ch_real(ch)].max(0) - lo4[ch_real(ch)].min(0), 1e-30)
+            slack[0] = max(slack[0], float((((l2 - lo) + (hi - h2)) / ext).max()))
             lo_all, hi_all = np.minimum(lo_all, l2), np.maximum(hi_all, h2)
         return lo_all, hi_all, stack_below + max(n_real - 1, 0)
+
+    def ch_real(ch):
+        return np.array([c >= 0 or ((~int(c)) & 7) != 0 for c in ch])
 
     _, _, need = rec(0, 1)
     assert (seen == 1).all()
     assert sorted(tris[:, 9].view(np.uint32)) == list(range(n))
     assert depth_seen[0] == max_depth
-    assert need == max_stack <= 48   # kStackMax (traverse.h)
+    assert need == max_stack <= 64   # kStackMax (traverse.h)
+    return slack[0]
 
 
 @pytest.mark.parametrize("scene_fn", [scenes.cornell_box, scenes.cornell_glass_mirror, lambda: scenes.heightfield(n=64, n_lights=3)])
