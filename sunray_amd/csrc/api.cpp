@@ -58,7 +58,7 @@ struct SrScene {
     std::vector<SrMeshInfo> mesh_infos;
     srh::FrameInstanceData fid;
     std::vector<srh::BuildTri> world_tris;
-    DeviceBuffer d_nodes, d_tris, d_shade, d_mesh_const, d_slot_of_gid, d_instances, d_emissive, d_indirection, d_transforms, d_misc;
+    DeviceBuffer d_nodes, d_tris, d_shade, d_mesh_const, d_slot_of_gid, d_instances, d_lights, d_misc;
     srd::DevScene dev{};
     SrBvhStats stats{};
     bool built = false;
@@ -168,7 +168,7 @@ int sr_scene_destroy(SrScene* s) {
     (void)hipDeviceSynchronize();
     for (auto& m : s->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     s->d_nodes.release(); s->d_tris.release(); s->d_shade.release(); s->d_mesh_const.release(); s->d_slot_of_gid.release(); s->d_instances.release();
-    s->d_emissive.release(); s->d_indirection.release(); s->d_transforms.release(); s->d_misc.release();
+    s->d_lights.release(); s->d_misc.release();
     for (auto& pool : s->events) for (auto& e : pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete s;
     return SR_OK;
@@ -266,18 +266,16 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     if ((rc = s->d_slot_of_gid.upload(slot_of_gid.data(), slot_of_gid.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_mesh_const.upload(mconst.data(), mconst.size() * sizeof(srd::DevMeshConst))) != SR_OK) return rc;
     if ((rc = s->d_instances.upload(dinst.data(), dinst.size() * sizeof(srd::DevInstance))) != SR_OK) return rc;
-    if ((rc = s->d_emissive.upload(s->emissive_tris.data(), s->emissive_tris.size() * sizeof(SrEmissiveTriangle))) != SR_OK) return rc;
-    if ((rc = s->d_indirection.upload(s->fid.emissive_entries.data(), s->fid.emissive_entries.size() * sizeof(SrEmissiveIndirectionEntry))) != SR_OK) return rc;
-    if ((rc = s->d_transforms.upload(s->fid.transforms.data(), s->fid.transforms.size() * sizeof(SrTransform))) != SR_OK) return rc;
+    std::vector<float> lights;
+    srh::light_table(s->fid, s->emissive_tris, lights);
+    if ((rc = s->d_lights.upload(lights.data(), lights.size() * 4)) != SR_OK) return rc;
     s->dev.nodes = (const float4*)s->d_nodes.p;
     s->dev.tris = (const float4*)s->d_tris.p;
     s->dev.shade = (const float4*)s->d_shade.p;
     s->dev.mesh_const = (const srd::DevMeshConst*)s->d_mesh_const.p;
     s->dev.slot_of_gid = (const uint32_t*)s->d_slot_of_gid.p;
     s->dev.instances = (const srd::DevInstance*)s->d_instances.p;
-    s->dev.emissive = (const SrEmissiveTriangle*)s->d_emissive.p;
-    s->dev.indirection = (const SrEmissiveIndirectionEntry*)s->d_indirection.p;
-    s->dev.transforms = (const SrTransform*)s->d_transforms.p;
+    s->dev.lights = (const srd::DevLight*)s->d_lights.p;
     s->dev.counters = (unsigned long long*)s->d_misc.p;
     s->dev.num_lights = (uint32_t)s->fid.emissive_entries.size();
     s->dev.n_tris = s->fid.n_triangles;

@@ -52,6 +52,8 @@ void world_to_object_3x3(const SrTransform& t, float out[9]);
 // Host twins of the shader pack helpers (rt_utils.slang:77-94), used to pre-pack per-mesh payload constants.
 uint32_t pack_unorm_4x8(float x, float y, float z, float w);
 uint32_t pack_half_2x16(float x, float y);
+// Per-light constants (DevLight in traverse.h): 16 floats per emissive_indirection entry.
+void light_table(const FrameInstanceData& fid, const std::vector<SrEmissiveTriangle>& emissive_tris, std::vector<float>& out);
 bool frame_instance_data(const std::vector<HostMesh>& meshes, const std::map<uint64_t, uint32_t>& slots,
                          const uint64_t* keys, const uint32_t* counts, uint32_t n_keys, const SrTransform* xforms,
                          FrameInstanceData& out, std::string& err);

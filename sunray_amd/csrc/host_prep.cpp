@@ -191,4 +191,33 @@ bool frame_instance_data(const std::vector<HostMesh>& meshes, const std::map<uin
     return true;
 }
 
+// DevLight table: what the shaders recompute per use from (emissive triangle, entity transform), in the
+// shaders' own operation order so the stored floats equal the ones the device would compute.
+void light_table(const FrameInstanceData& fid, const std::vector<SrEmissiveTriangle>& emissive_tris, std::vector<float>& out) {
+    out.assign(fid.emissive_entries.size() * 16, 0.0f);
+    for (size_t i = 0; i < fid.emissive_entries.size(); i++) {
+        const SrEmissiveIndirectionEntry& e = fid.emissive_entries[i];
+        const SrEmissiveTriangle& t = emissive_tris[e.blas_tri_index];
+        const float* m = fid.transforms[e.entity_id].m;
+        float w[3][3];
+        const float* v[3] = {t.v0, t.v1, t.v2};
+        for (int k = 0; k < 3; k++) {   // transform_point (rt_utils.slang:278-281)
+            w[k][0] = ((m[0] * v[k][0] + m[1] * v[k][1]) + m[2] * v[k][2]) + m[3] * 1.0f;
+            w[k][1] = ((m[4] * v[k][0] + m[5] * v[k][1]) + m[6] * v[k][2]) + m[7] * 1.0f;
+            w[k][2] = ((m[8] * v[k][0] + m[9] * v[k][1]) + m[10] * v[k][2]) + m[11] * 1.0f;
+        }
+        const float e1[3] = {w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2]};
+        const float e2[3] = {w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2]};
+        const float c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const float dd = (c[0] * c[0] + c[1] * c[1]) + c[2] * c[2];
+        const float len = sqrtf(dd);
+        const float r = 1.0f / len;
+        float* q = &out[i * 16];
+        q[0] = w[0][0]; q[1] = w[0][1]; q[2] = w[0][2]; q[3] = 0.5f * len;
+        q[4] = w[1][0]; q[5] = w[1][1]; q[6] = w[1][2]; q[7] = c[0] * r;
+        q[8] = w[2][0]; q[9] = w[2][1]; q[10] = w[2][2]; q[11] = c[1] * r;
+        q[12] = t.emission[0]; q[13] = t.emission[1]; q[14] = t.emission[2]; q[15] = c[2] * r;
+    }
+}
+
 }  // namespace srh

@@ -158,22 +158,20 @@ SRD void store48(T* p, const T& v) {
     d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
 }
 
-SRD f3 light_emission(const DevScene& sc, uint32_t indirection_idx) {
-    const uint32_t slot = sc.indirection[indirection_idx].blas_tri_index;
-    return ld3(sc.emissive[slot].emission);
-}
-// Uniformly sampled point on emissive triangle `idx` (ray_gen_ris.slang:191-210,346-362;
-// ray_gen_final.slang:330-351). The random draws stay at the call sites: their order is semantic.
-struct LightTri { f3 wv0, wv1, wv2, emission; };
+SRD f3 light_emission(const DevScene& sc, uint32_t indirection_idx) { return ld3(sc.lights[indirection_idx].emission); }
+// Emissive triangle `idx` of the light list (ray_gen_ris.slang:191-210,346-362; ray_gen_final.slang:330-351):
+// world-space vertices, area and normal come precomputed from the scene build (DevLight). The random
+// draws stay at the call sites: their order is semantic.
+struct LightTri { f3 wv0, wv1, wv2, emission, normal; float area; };
 SRD LightTri fetch_light(const DevScene& sc, uint32_t idx) {
-    const SrEmissiveIndirectionEntry e = sc.indirection[idx];
-    const SrEmissiveTriangle* lt = sc.emissive + e.blas_tri_index;
-    const float* xf = sc.transforms[e.entity_id].m;
+    const float4* q = reinterpret_cast<const float4*>(sc.lights + idx);
+    const float4 a = q[0], b = q[1], c = q[2], e = q[3];
     LightTri r;
-    r.wv0 = transform_point(xf, ld3(lt->v0));
-    r.wv1 = transform_point(xf, ld3(lt->v1));
-    r.wv2 = transform_point(xf, ld3(lt->v2));
-    r.emission = ld3(lt->emission);
+    r.wv0 = mk3(a.x, a.y, a.z); r.area = a.w;
+    r.wv1 = mk3(b.x, b.y, b.z);
+    r.wv2 = mk3(c.x, c.y, c.z);
+    r.emission = mk3(e.x, e.y, e.z);
+    r.normal = mk3(b.w, c.w, e.w);
     return r;
 }
 
@@ -288,14 +286,13 @@ __global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
                     uint32_t cand_idx = (uint32_t)(rnd(rng) * (float)num_lights);
                     if (cand_idx > num_lights - 1) cand_idx = num_lights - 1;
                     const LightTri lt = fetch_light(sc, cand_idx);
-                    const f3 edge1 = lt.wv1 - lt.wv0, edge2 = lt.wv2 - lt.wv0;
-                    const float cand_area = 0.5f * len3(cross3(edge1, edge2));
+                    const float cand_area = lt.area;
                     const float sqr1 = sqrtf(rnd(rng));
                     const float u = 1.0f - sqr1;
                     const float v = rnd(rng) * sqr1;
                     const float w = 1.0f - u - v;
                     const f3 cand_pos = lt.wv0 * u + lt.wv1 * v + lt.wv2 * w;
-                    const f3 cand_normal = norm3(cross3(lt.wv1 - lt.wv0, lt.wv2 - lt.wv0));
+                    const f3 cand_normal = lt.normal;
                     const f3 f_y = eval_unshadowed_light(hitPos, hit_normal, V_view, hit_albedo, roughness, metallic, lt.emission, cand_pos, cand_normal);
                     const float p_hat = maxc(f_y);
                     const float p_y = 1.0f / fmaxf((float)num_lights * cand_area, 0.0001f);
@@ -376,9 +373,8 @@ __global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
                         const float nv = rnd(rng) * sq;
                         const float nw = 1.0f - nu - nv;
                         const f3 nee_pos = lt.wv0 * nu + lt.wv1 * nv + lt.wv2 * nw;
-                        const f3 ncr = cross3(lt.wv1 - lt.wv0, lt.wv2 - lt.wv0);
-                        const f3 nee_normal = norm3(ncr);
-                        const float nee_area = 0.5f * len3(ncr);
+                        const f3 nee_normal = lt.normal;
+                        const float nee_area = lt.area;
                         f3 to_light = nee_pos - sample_pos;
                         const float nee_dist = fmaxf(len3(to_light), 0.0001f);
                         to_light = to_light / nee_dist;
@@ -624,9 +620,7 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
                         uint32_t light_idx = (uint32_t)(rnd(rng) * (float)num_lights);
                         if (light_idx > num_lights - 1) light_idx = num_lights - 1;
                         const LightTri lt = fetch_light(sc, light_idx);
-                        const f3 edge1 = lt.wv1 - lt.wv0, edge2 = lt.wv2 - lt.wv0;
-                        const f3 lcr = cross3(edge1, edge2);
-                        const float light_area = 0.5f * len3(lcr);
+                        const float light_area = lt.area;
                         const float r1_nee = rnd(rng);
                         const float r2_nee = rnd(rng);
                         const float sqr1 = sqrtf(r1_nee);
@@ -634,7 +628,7 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
                         const float v = r2_nee * sqr1;
                         const float w = 1.0f - u - v;
                         const f3 light_pos = lt.wv0 * u + lt.wv1 * v + lt.wv2 * w;
-                        const f3 light_normal = norm3(lcr);
+                        const f3 light_normal = lt.normal;
                         f3 shadow_ray_dir = light_pos - hitPos;
                         const float light_dist = len3(shadow_ray_dir);
                         shadow_ray_dir = shadow_ray_dir / light_dist;

@@ -39,15 +39,24 @@ struct DevMeshConst {  // 32 B: the per-mesh constants of the 32-byte RayPayload
     uint32_t _pad[2];
 };
 
+// One emissive triangle of the frame's light list (= one emissive_indirection entry), with everything the
+// shaders derive from it per use hoisted to scene build time — same operations, same order, same bits
+// (ray_gen_ris.slang:192-210,347-362; ray_gen_final.slang:331-351): world vertices via transform_point,
+// area = 0.5*length(cross(e1,e2)), normal = normalize(cross(e1,e2)), emission.
+struct DevLight {   // 64 B
+    float wv0[3], area;
+    float wv1[3], nx;
+    float wv2[3], ny;
+    float emission[3], nz;
+};
+
 struct DevScene {
     const float4* nodes;
     const float4* tris;
     const float4* shade;
     const DevMeshConst* mesh_const;
     const DevInstance* instances;
-    const SrEmissiveTriangle* emissive;
-    const SrEmissiveIndirectionEntry* indirection;
-    const SrTransform* transforms;
+    const DevLight* lights;        // [num_lights]
     const uint32_t* slot_of_gid;   // global triangle index -> leaf-order slot (sr_shade_closest_hit only)
     unsigned long long* counters;  // [0]=closest queries [1]=any queries [2]=boxes [3]=tris
     uint32_t num_lights;
