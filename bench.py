@@ -93,16 +93,23 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = "cuda:%d" % local_rank
+    # Rehearsal switch for a box with ONE GPU: every rank renders on cuda:0 and the gather goes through
+    # gloo (host staging). Never used by the driver's runs.
+    rehearsal = os.environ.get("SUNRAY_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = "cuda:%d" % dev_index
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(device))
 
     W, H = args.width, args.height
     desc = scenes.heightfield(args.grid)
     blue_noise = scenes.white_noise_rgba8()
-    scene = rt.Scene(local_rank).load(desc)
+    scene = rt.Scene(dev_index).load(desc)
     st = scene.bvh_stats()
     frame = rt.DeviceFrame(W, H, blue_noise, device=device)
     cfg = abi.SrTraceConfig.reference()
@@ -117,7 +124,12 @@ def main():
         state["prev"] = list(m.view_proj)
         sd.render_strip(scene, frame, m, state["frame"], cfg, world, rank, abi.TRACE_FLAG_UNCOUNTED)
         if world > 1:
-            sd.gather_strips(frame.raw_color, W, H, world, rank, out=gathered, scratch=scratch)
+            if rehearsal:
+                torch.cuda.synchronize()
+                full = sd.gather_strips(frame.raw_color.cpu(), W, H, world, rank)
+                gathered[: H * W].copy_(full)
+            else:
+                sd.gather_strips(frame.raw_color, W, H, world, rank, out=gathered, scratch=scratch)
         state["frame"] += 1
 
     def fence():
@@ -134,10 +146,18 @@ def main():
     per_kind = {}
     m_i = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, state["prev"])
     y0, h = sd.strip_rows(H, world, rank)
-    for kind, fn in ((KIND_RIS, scene.trace_ris), (KIND_FINAL, scene.trace_final)):
-        scene.reset_counters()
-        fn(frame, m_i, state["frame"], cfg, tile=(y0, h))
-        per_kind[kind] = scene.counters()
+    import copy
+    halo_cfg = copy.copy(cfg)
+    halo_cfg.flags = cfg.flags | abi.TRACE_FLAG_UNCOUNTED
+    scene.reset_counters()
+    scene.trace_ris(frame, m_i, state["frame"], cfg, tile=(y0, h))
+    per_kind[KIND_RIS] = scene.counters()
+    if world > 1:   # keep the halo rows' reservoirs current: they are next frame's temporal history
+        for band in sd.halo_bands(H, y0, h):
+            scene.trace_ris(frame, m_i, state["frame"], halo_cfg, tile=band)
+    scene.reset_counters()
+    scene.trace_final(frame, m_i, state["frame"], cfg, tile=(y0, h))
+    per_kind[KIND_FINAL] = scene.counters()
     state["prev"] = list(m_i.view_proj)
     state["frame"] += 1
     scene.set_instrumented(False)
@@ -156,13 +176,20 @@ def main():
     ris_ms, ris_n = scene.read_timing(KIND_RIS)
     fin_ms, fin_n = scene.read_timing(KIND_FINAL)
 
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    rays = torch.tensor([float(c.closest_queries + c.any_queries), float(c.closest_queries), float(c.any_queries)], dtype=torch.float64, device=device)
+    red_dev = "cpu" if rehearsal else device
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    rays = torch.tensor([float(c.closest_queries + c.any_queries), float(c.closest_queries), float(c.any_queries)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed = float(t_el.item())
     total_rays, total_closest, total_any = [float(x) for x in rays.tolist()]
+
+    # CRC of the last frame's full fp32 radiance image (outside the timed region): N-GPU runs of the same
+    # --steps/--warmup must print the same value as the 1-GPU run (tiling is bit-exact).
+    import zlib
+    final_image = gathered[: H * W] if world > 1 else frame.raw_color
+    frame_crc = "%08x" % (zlib.crc32(final_image.cpu().numpy().tobytes()) & 0xFFFFFFFF)
 
     if rank == 0:
         # dominant kernel of this rank: the pass with the larger summed device time
@@ -197,6 +224,7 @@ def main():
                 "any_per_frame": total_any / args.steps,
                 "parallelism": "rows split into %d strips, RIS halo %d rows recomputed, radiance all-gathered over RCCL" % (world, sd.SPATIAL_HALO) if world > 1 else "single GPU",
                 "bvh_build_ms_host": st.build_ms,
+                "last_frame_crc32": frame_crc,
             },
             "roofline": {
                 "bound": "hbm",
