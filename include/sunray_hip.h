@@ -309,6 +309,8 @@ typedef struct SrBvhStats {
     uint64_t tri_bytes;   /* 48 B per triangle record */
     uint32_t max_depth;   /* of the 4-wide tree */
     float sah_cost;
+    uint32_t max_stack;   /* worst-case traversal stack entries (sizes the kernels' LDS stack) */
+    uint32_t _pad;
     double build_ms;
 } SrBvhStats;
 int sr_scene_bvh_stats(const SrScene* scene, SrBvhStats* out);

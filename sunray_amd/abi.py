@@ -80,7 +80,7 @@ class SrRayCounters(C.Structure):
 class SrBvhStats(C.Structure):
     _fields_ = [("n_triangles", C.c_uint64), ("n_nodes", C.c_uint64), ("node_bytes", C.c_uint64),
                 ("tri_bytes", C.c_uint64), ("max_depth", C.c_uint32), ("sah_cost", C.c_float),
-                ("build_ms", C.c_double)]
+                ("max_stack", C.c_uint32), ("_pad", C.c_uint32), ("build_ms", C.c_double)]
 
 
 def material(base_color=(0.8, 0.8, 0.8, 1.0), metallic=0.0, roughness=0.5, emissive_factor=(0.0, 0.0, 0.0),

@@ -285,6 +285,7 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     s->stats.node_bytes = (uint64_t)bvh.n_nodes * 64;
     s->stats.tri_bytes = (uint64_t)s->fid.n_triangles * 48;
     s->stats.max_depth = bvh.max_depth;
+    s->stats.max_stack = bvh.max_stack;
     s->stack_entries = (int)((std::max(bvh.max_stack, 4u) + 3u) & ~3u);
     s->stats.sah_cost = bvh.sah_cost;
     s->stats.build_ms = bvh.build_ms;

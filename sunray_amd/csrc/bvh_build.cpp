@@ -231,9 +231,23 @@ inline float area_of(const Child4& c) {
 struct Collapser {
     const std::vector<float>& n2;
     std::vector<uint32_t>& out;   // 16 dwords per node
+    std::vector<uint8_t> height;  // of each binary inner node = stack entries a purely binary walk below it needs
     uint32_t max_depth = 0;
-    // returns the worst-case number of stack entries a traversal below (and including) this node needs
-    uint32_t emit(int node2, uint32_t depth, int* out_index) {
+    uint32_t height_of(int node2) {
+        uint32_t h = 0;
+        for (int c = 0; c < 2; c++) {
+            int ref; memcpy(&ref, &n2[(size_t)node2 * 16 + 12 + c], 4);
+            if (ref >= 0) h = std::max(h, height_of(ref));
+        }
+        height[node2] = (uint8_t)(h + 1);
+        return h + 1;
+    }
+    uint32_t need_of(const Child4& c) const { return c.ref >= 0 ? height[c.ref] : 0u; }
+    // `budget` = stack entries a traversal may use below (and including) this node. A node with k
+    // children can leave k-1 entries on the stack while a child is walked, so wide nodes are only
+    // formed where the budget allows; the binary tree below always fits (height <= kMaxBinaryDepth).
+    // Returns the worst-case number of entries actually needed.
+    uint32_t emit(int node2, uint32_t depth, uint32_t budget, int* out_index) {
         Child4 kids[4];
         int nk = 0;
         kids[nk++] = child_of(&n2[(size_t)node2 * 16], 0);
@@ -242,9 +256,13 @@ struct Collapser {
             int best = -1; float best_area = -1.0f;
             for (int i = 0; i < nk; i++) if (kids[i].ref >= 0) { const float a = area_of(kids[i]); if (a > best_area) { best_area = a; best = i; } }
             if (best < 0) break;
-            const int inner = kids[best].ref;
-            kids[best] = child_of(&n2[(size_t)inner * 16], 0);
-            kids[nk++] = child_of(&n2[(size_t)inner * 16], 1);
+            const Child4 ca = child_of(&n2[(size_t)kids[best].ref * 16], 0), cb = child_of(&n2[(size_t)kids[best].ref * 16], 1);
+            // with nk+1 children every child subtree must fit in budget - nk entries
+            bool fits = need_of(ca) + (uint32_t)nk <= budget && need_of(cb) + (uint32_t)nk <= budget;
+            for (int i = 0; i < nk && fits; i++) if (i != best && need_of(kids[i]) + (uint32_t)nk > budget) fits = false;
+            if (!fits) break;
+            kids[best] = ca;
+            kids[nk++] = cb;
         }
         bool real[4] = {false, false, false, false};
         int n_real = 0;
@@ -309,7 +327,7 @@ struct Collapser {
             if (i < nk && real[i]) {
                 if (kids[i].ref >= 0) {
                     int idx = 0;
-                    below = std::max(below, emit(kids[i].ref, depth + 1, &idx));
+                    below = std::max(below, emit(kids[i].ref, depth + 1, budget - (uint32_t)(n_real - 1), &idx));
                     refs[i] = idx;
                 } else refs[i] = kids[i].ref;
             }
@@ -324,11 +342,13 @@ struct Collapser {
 };
 }  // namespace
 
-static void collapse_to_bvh4(BvhResult& res) {
+static void collapse_to_bvh4(BvhResult& res, uint32_t stack_budget) {
     res.nodes.clear();
-    Collapser c{res.nodes2, res.nodes};
+    Collapser c{res.nodes2, res.nodes, {}, 0};
+    c.height.assign(res.nodes2.size() / 16, 0);
+    c.height_of(0);
     int root = 0;
-    res.max_stack = c.emit(0, 1, &root);
+    res.max_stack = c.emit(0, 1, stack_budget, &root);
     res.max_depth = c.max_depth;
     res.n_nodes = (uint32_t)(res.nodes.size() / 16);
 }
@@ -401,7 +421,7 @@ void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult&
     }
     res.nodes2.swap(top.nodes);
     res.sah_cost = (float)top.cost;
-    collapse_to_bvh4(res);
+    collapse_to_bvh4(res, max_depth);
     res.order = b.order;
     res.tris.resize((size_t)n * 12);
     for (uint32_t i = 0; i < n; i++) {

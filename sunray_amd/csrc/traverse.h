@@ -23,7 +23,7 @@
 
 namespace srd {
 
-constexpr int kStackMax = 64;         // the scene build fails if a traversal could need more LDS stack entries per lane;
+constexpr int kStackMax = 32;         // LDS stack entries per lane the builder shapes the tree for (= kMaxBinaryDepth);
                                       // launches size the dynamic LDS stack to what the scene's tree actually needs
 constexpr int kMaxBinaryDepth = 32;  // depth bound of the binary tree the 4-wide tree is collapsed from
 constexpr int kSentinel = 0x7fffffff;

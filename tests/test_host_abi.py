@@ -136,7 +136,7 @@ def _check_bvh(nodes, tris, max_depth, max_stack):
     assert (seen == 1).all()
     assert sorted(tris[:, 9].view(np.uint32)) == list(range(n))
     assert depth_seen[0] == max_depth
-    assert need == max_stack <= 64   # kStackMax (traverse.h)
+    assert need == max_stack <= 32   # kStackMax (traverse.h): the builder narrows nodes where the budget is tight
     return slack[0]
 
 
