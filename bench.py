@@ -43,6 +43,22 @@ def algorithmic_bytes(c, n_pixels, which):
     return b
 
 
+def pmc_traffic(dom, world, W, H, grid):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/
+    r01_pmc_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 --pmc runs of this
+    very script and corrected as MI355X_MICROARCH.md §HBM prescribes). Counters cannot be read from inside
+    a normal run, so this is the profiled value for the default single-GPU workload, else null."""
+    if world != 1 or (W, H, grid) != (1920, 1080, 708):
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        with open(path) as fh:
+            k = json.load(fh)["kernels"]["final_kernel" if dom == KIND_FINAL else "ris_kernel"]
+        return k["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(desc, W, H, blue_noise, budget_s=12.0, max_frames=8):
     """The oracle (our CPU restatement: the reference has no CPU path) timed on this host's cores on
     the same scene / extent / constants; whole frames until ~budget_s of work."""
@@ -233,7 +249,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(dom, world, W, H, args.grid),
                 "avg_launch_ms": avg_ms,
                 "launches_timed": dom_n,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
