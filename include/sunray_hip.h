@@ -359,6 +359,42 @@ int sr_trace_ris(const SrRtParams* params, void* stream);
  * stream when config.enable_restir != 0 (the reservoir hand-off edge, lib.rs:1688-1690). */
 int sr_trace_final(const SrRtParams* params, void* stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Post-RT compute chain: what turns raw_color into the presented RGBA8 image    */
+/* ------------------------------------------------------------------------------------------ */
+
+/* The compute passes Renderer::build_unified_graph appends after the two ray-tracing passes
+ * (src/lib.rs:1576-1615). Images keep the reference's formats (lib.rs:452-461,1492-1516): the
+ * accumulation and denoise ping-pong images are B10G11R11_UFLOAT_PACK32, the output R8G8B8A8_UNORM.
+ * raw_color is this library's fp32 RGBA radiance; it is rounded to B10G11R11 when read, which is
+ * where the reference quantises it (its raw_color image has that format). All device pointers. */
+typedef struct SrPostParams {
+    const float* raw_color;          /* 4*W*H floats, written by sr_trace_final                     */
+    const uint32_t* motion_vec_img;  /* R16G16_SFLOAT, written by sr_trace_ris                      */
+    const uint16_t* depth_img;       /* R16_SFLOAT                                                   */
+    const uint32_t* normal_img;      /* R8G8B8A8_SNORM (roughness in .a)                             */
+    const uint32_t* diffuse_img;     /* B10G11R11                                                    */
+    uint32_t* accum[2];              /* temporal ping-pong: target = frame_count % 2 (lib.rs:1360-1361) */
+    uint32_t* denoise[2];            /* a-trous ping-pong a / b (lib.rs:1817-1826)                    */
+    uint32_t* output_rgba8;          /* W*H, R8G8B8A8_UNORM                                          */
+    uint32_t frame_count;            /* relative_frame_count                                         */
+    uint32_t width, height;
+    float exposure;                  /* EXPOSURE = 1.0 (lib.rs:44)                                   */
+    uint32_t denoise_passes;         /* DENOISE_PASSES = 4 (lib.rs:42); step width 1 << pass          */
+    uint32_t _pad;
+} SrPostParams;
+
+/* "temporal_accumulation" (shaders/temporal_accumulation.slang:60-132, lib.rs:1761-1798):
+ * 3x3 luma-gated neighbourhood clamp of the bilinearly reprojected history, lerp 0.14. */
+int sr_post_temporal(const SrPostParams* params, void* stream);
+/* "denoise_0..N-1" (shaders/denoise.slang:29-116, lib.rs:1800-1870): 5x5 a-trous B-spline with
+ * depth / normal / albedo / luma edge stopping on albedo-demodulated illumination. Pass 0 reads
+ * accum[frame_count % 2]; the result of the last pass is in denoise[(denoise_passes - 1) % 2]. */
+int sr_post_denoise(const SrPostParams* params, void* stream);
+/* "postprocess" (shaders/postprocess.slang:22-42, lib.rs:1872-1906): NaN/Inf scrub, exposure,
+ * ACES (Narkowicz), gamma 1/2.2, RGBA8 store. Reads denoise[(denoise_passes - 1) % 2]. */
+int sr_post_tonemap(const SrPostParams* params, void* stream);
+
 /* Ray counters since the last reset (device-side atomics, read back synchronously). */
 int sr_scene_reset_counters(SrScene* scene, void* stream);
 int sr_scene_read_counters(SrScene* scene, void* stream, SrRayCounters* out);
@@ -393,6 +429,7 @@ static_assert(sizeof(SrReservoir) == 48 && sizeof(SrReservoirGI) == 48, "T7");
 static_assert(sizeof(SrRayPayload) == 32, "T8");
 static_assert(sizeof(SrRay) == 32 && sizeof(SrHit) == 16, "ray/hit");
 static_assert(sizeof(SrTraceConfig) == 32 && sizeof(SrRtParams) == 160, "T9");
+static_assert(sizeof(SrPostParams) == 104, "post params");
 #endif
 
 #endif /* SUNRAY_HIP_H */

@@ -34,6 +34,10 @@ def lib():
         L.orc_f16_to_f32.restype = C.c_float
         L.orc_exp.restype = C.c_float
         L.orc_exp.argtypes = [C.c_float]
+        L.orc_log.restype = C.c_float
+        L.orc_log.argtypes = [C.c_float]
+        L.orc_pow.restype = C.c_float
+        L.orc_pow.argtypes = [C.c_float, C.c_float]
         L.orc_smith_v_ggx.restype = C.c_float
         L.orc_smith_g1_ggx.restype = C.c_float
         L.orc_smoothstep.restype = C.c_float
@@ -210,6 +214,20 @@ class HostFrame:
         self.reservoirs = [np.zeros(n, dtype=abi.RESERVOIR), np.zeros(n, dtype=abi.RESERVOIR)]
         self.reservoirs_gi = [np.zeros(n, dtype=abi.RESERVOIR_GI), np.zeros(n, dtype=abi.RESERVOIR_GI)]
         self.blue_noise = np.ascontiguousarray(blue_noise, dtype=np.uint8)
+        self.accum = [np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)]
+        self.denoise = [np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)]
+        self.output = np.zeros(n, dtype=np.uint32)
+
+
+def post_chain(frame, frame_count, exposure=1.0, denoise_passes=4, stages=("temporal", "denoise", "tonemap")):
+    """The oracle's temporal_accumulation -> a-trous denoise -> postprocess on a HostFrame."""
+    p = abi.post_params(frame, frame_count, lambda a: a.ctypes.data, exposure, denoise_passes)
+    if "temporal" in stages:
+        lib().orc_post_temporal(C.byref(p))
+    if "denoise" in stages:
+        lib().orc_post_denoise(C.byref(p))
+    if "tonemap" in stages:
+        lib().orc_post_tonemap(C.byref(p))
 
 
 def camera_matrices(pos, target, fov_y, width, height, prev_view_proj=None):

@@ -8,6 +8,7 @@
 #include "orc_scene.h"
 
 using namespace orc;
+namespace orc { void post_temporal(const SrPostParams&); void post_denoise(const SrPostParams&); void post_tonemap(const SrPostParams&); }
 
 extern "C" {
 
@@ -58,6 +59,11 @@ void orc_shade_closest_hit(void* sp, const SrHit* hits, uint32_t n, SrRayPayload
 }
 void orc_trace_ris(void* sp, const SrRtParams* p) { trace_ris(*(Scene*)sp, *p); }
 void orc_trace_final(void* sp, const SrRtParams* p) { trace_final(*(Scene*)sp, *p); }
+void orc_post_temporal(const SrPostParams* p) { post_temporal(*p); }
+void orc_post_denoise(const SrPostParams* p) { post_denoise(*p); }
+void orc_post_tonemap(const SrPostParams* p) { post_tonemap(*p); }
+float orc_log(float x) { return log_f(x); }
+float orc_pow(float x, float y) { return pow_f(x, y); }
 void orc_reset_counters(void* sp) { ((Scene*)sp)->counters = Counters{}; }
 void orc_read_counters(void* sp, SrRayCounters* out) {
     const Counters& c = ((Scene*)sp)->counters;

@@ -116,6 +116,39 @@ static inline float exp_f(float x) {
     return y * u2f((uint32_t)(k2 + 127) << 23);
 }
 
+// log (natural), pinned like sin/cos/exp: Cephes logf, polynomial spelled with fmaf. Used by pow(x, 1/2.2)
+// of postprocess.slang:39, restated as exp(y * log(x)).
+static inline float log_f(float x) {
+    if (!(x == x)) return x;
+    if (x < 0.0f) return NAN;
+    if (x == 0.0f) return -INFINITY;
+    if (x == INFINITY) return x;
+    int e = 0;
+    if (x < 1.17549435e-38f) { x = x * 33554432.0f; e = -25; }   // denormal: scale by 2^25
+    uint32_t u = f2u(x);
+    e += (int)(u >> 23) - 126;
+    float m = u2f((u & 0x007fffffu) | 0x3f000000u);               // mantissa in [0.5, 1)
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; }
+    else m = m - 1.0f;
+    const float z = m * m;
+    float y = fmaf(7.0376836292e-2f, m, -1.1514610310e-1f);
+    y = fmaf(y, m, 1.1676998740e-1f);
+    y = fmaf(y, m, -1.2420140846e-1f);
+    y = fmaf(y, m, 1.4249322787e-1f);
+    y = fmaf(y, m, -1.6668057665e-1f);
+    y = fmaf(y, m, 2.0000714765e-1f);
+    y = fmaf(y, m, -2.4999993993e-1f);
+    y = fmaf(y, m, 3.3333331174e-1f);
+    y = y * m * z;
+    const float fe = (float)e;
+    y = fmaf(-2.12194440e-4f, fe, y);
+    y = fmaf(-0.5f, z, y);
+    float r = m + y;
+    r = fmaf(0.693359375f, fe, r);
+    return r;
+}
+static inline float pow_f(float x, float y) { return exp_f(y * log_f(x)); }
+
 // ---- IEEE binary16 (f32tof16 / f16tof32, rt_utils.slang:89-94), round-to-nearest-even ---------
 static inline uint32_t f32_to_f16(float f) {
     uint32_t u = f2u(f);

@@ -14,7 +14,7 @@ SYMBOLS = [
     "sr_last_error", "sr_version", "sr_camera_matrices", "sr_material_new", "sr_emissive_triangles_from_mesh",
     "sr_trace_config_default", "sr_scene_create", "sr_scene_destroy", "sr_scene_add_mesh", "sr_scene_set_instances",
     "sr_scene_get_tables", "sr_scene_bvh_stats", "sr_scene_resolve_triangle", "sr_host_bvh_build", "sr_host_bvh_get",
-    "sr_host_bvh_destroy", "sr_trace_closest", "sr_trace_any", "sr_shade_closest_hit", "sr_trace_ris", "sr_trace_final",
+    "sr_host_bvh_destroy", "sr_trace_closest", "sr_trace_any", "sr_shade_closest_hit", "sr_trace_ris", "sr_trace_final", "sr_post_temporal", "sr_post_denoise", "sr_post_tonemap",
     "sr_scene_reset_counters", "sr_scene_read_counters", "sr_scene_set_instrumented", "sr_scene_debug_worst_ray", "sr_scene_enable_timing",
     "sr_scene_read_timing",
 ]

@@ -72,6 +72,28 @@ class SrRtParams(C.Structure):  # T9
                 ("config", SrTraceConfig)]
 
 
+class SrPostParams(C.Structure):  # post-RT compute chain (temporal accumulation, a-trous denoise, tonemap)
+    _fields_ = [("raw_color", C.c_void_p), ("motion_vec_img", C.c_void_p), ("depth_img", C.c_void_p),
+                ("normal_img", C.c_void_p), ("diffuse_img", C.c_void_p), ("accum", C.c_void_p * 2),
+                ("denoise", C.c_void_p * 2), ("output_rgba8", C.c_void_p), ("frame_count", C.c_uint32),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("exposure", C.c_float),
+                ("denoise_passes", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+def post_params(frame, frame_count, ptr, exposure=1.0, denoise_passes=4):
+    """SrPostParams over a HostFrame / DeviceFrame; `ptr(buffer)` gives the address of a buffer.
+    Defaults are the reference's EXPOSURE and DENOISE_PASSES (src/lib.rs:42,44)."""
+    p = SrPostParams()
+    p.raw_color, p.motion_vec_img = ptr(frame.raw_color), ptr(frame.motion)
+    p.depth_img, p.normal_img, p.diffuse_img = ptr(frame.depth), ptr(frame.normal), ptr(frame.diffuse)
+    p.accum[0], p.accum[1] = ptr(frame.accum[0]), ptr(frame.accum[1])
+    p.denoise[0], p.denoise[1] = ptr(frame.denoise[0]), ptr(frame.denoise[1])
+    p.output_rgba8 = ptr(frame.output)
+    p.frame_count, p.width, p.height = frame_count, frame.width, frame.height
+    p.exposure, p.denoise_passes = exposure, denoise_passes
+    return p
+
+
 class SrRayCounters(C.Structure):
     _fields_ = [("closest_queries", C.c_uint64), ("any_queries", C.c_uint64),
                 ("boxes_tested", C.c_uint64), ("tris_tested", C.c_uint64)]

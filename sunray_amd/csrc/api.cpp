@@ -417,6 +417,40 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
 int sr_trace_ris(const SrRtParams* params, void* stream) { return run_pass(params, 0, stream); }
 int sr_trace_final(const SrRtParams* params, void* stream) { return run_pass(params, 1, stream); }
 
+static int check_post(const SrPostParams* p, const char* name, bool need_rt, bool need_gbuffer) {
+    if (!p) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": params is null");
+    if (p->width == 0 || p->height == 0) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": extent not set");
+    if ((uint64_t)p->width * p->height >= (1ull << 31)) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": extent too large");
+    if (!p->accum[0] || !p->accum[1] || !p->denoise[0] || !p->denoise[1]) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": ping-pong image pointer is null");
+    if (need_rt && (!p->raw_color || !p->motion_vec_img)) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": raw_color / motion_vec_img is null");
+    if (need_gbuffer && (!p->depth_img || !p->normal_img || !p->diffuse_img)) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": G-buffer image pointer is null");
+    if (p->denoise_passes == 0 || p->denoise_passes > 8) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": denoise_passes must be 1..8");
+    return SR_OK;
+}
+
+int sr_post_temporal(const SrPostParams* p, void* stream) {
+    int rc = check_post(p, "temporal_accumulation", true, false);
+    if (rc != SR_OK) return rc;
+    int e = srk_launch_post_temporal(*p, (hipStream_t)stream);
+    if (e != 0) return fail(SR_ERR_HIP, std::string("temporal_accumulation launch: ") + hipGetErrorString((hipError_t)e));
+    return SR_OK;
+}
+int sr_post_denoise(const SrPostParams* p, void* stream) {
+    int rc = check_post(p, "denoise", false, true);
+    if (rc != SR_OK) return rc;
+    int e = srk_launch_post_denoise(*p, (hipStream_t)stream);
+    if (e != 0) return fail(SR_ERR_HIP, std::string("denoise launch: ") + hipGetErrorString((hipError_t)e));
+    return SR_OK;
+}
+int sr_post_tonemap(const SrPostParams* p, void* stream) {
+    int rc = check_post(p, "postprocess", false, false);
+    if (rc != SR_OK) return rc;
+    if (!p->output_rgba8) return fail(SR_ERR_INVALID_ARG, "postprocess: output image pointer is null");
+    int e = srk_launch_post_tonemap(*p, (hipStream_t)stream);
+    if (e != 0) return fail(SR_ERR_HIP, std::string("postprocess launch: ") + hipGetErrorString((hipError_t)e));
+    return SR_OK;
+}
+
 int sr_scene_reset_counters(SrScene* s, void* stream) {
     if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_reset_counters: scene is null");
     int rc = bind_device(s);

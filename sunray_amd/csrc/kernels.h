@@ -34,3 +34,7 @@ int srk_launch_trace(const srd::DevScene& sc, const SrRay* rays, uint32_t n, SrH
                      uint32_t* queue_head, int any, int stats, int n_blocks, int stack_entries, hipStream_t stream);
 int srk_launch_shade(const srd::DevScene& sc, const SrHit* hits, uint32_t n, SrRayPayload* out, hipStream_t stream);
 int srk_launch_pass(const srd::PassArgs& args, int which, int stats, int stack_entries, hipStream_t stream);
+
+int srk_launch_post_temporal(const SrPostParams& p, hipStream_t stream);
+int srk_launch_post_denoise(const SrPostParams& p, hipStream_t stream);
+int srk_launch_post_tonemap(const SrPostParams& p, hipStream_t stream);

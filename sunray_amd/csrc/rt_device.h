@@ -93,6 +93,40 @@ SRD float exp_pinned(float x) {
     return y * __uint_as_float((uint32_t)(k2 + 127) << 23);
 }
 
+// natural log pinned like sin/cos/exp (Cephes logf, polynomial as explicit fma); pow(x, y) = exp(y * log(x))
+// restates the only non-integer pow of the path (postprocess.slang:39, gamma 1/2.2).
+SRD float log_pinned(float x) {
+    if (!(x == x)) return x;
+    if (x < 0.0f) return __builtin_nanf("");
+    if (x == 0.0f) return -__builtin_inff();
+    if (x == __builtin_inff()) return x;
+    int e = 0;
+    if (x < 1.17549435e-38f) { x = x * 33554432.0f; e = -25; }
+    const uint32_t u = __float_as_uint(x);
+    e += (int)(u >> 23) - 126;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; }
+    else m = m - 1.0f;
+    const float z = m * m;
+    float y = fmaf(7.0376836292e-2f, m, -1.1514610310e-1f);
+    y = fmaf(y, m, 1.1676998740e-1f);
+    y = fmaf(y, m, -1.2420140846e-1f);
+    y = fmaf(y, m, 1.4249322787e-1f);
+    y = fmaf(y, m, -1.6668057665e-1f);
+    y = fmaf(y, m, 2.0000714765e-1f);
+    y = fmaf(y, m, -2.4999993993e-1f);
+    y = fmaf(y, m, 3.3333331174e-1f);
+    y = y * m * z;
+    const float fe = (float)e;
+    y = fmaf(-2.12194440e-4f, fe, y);
+    y = fmaf(-0.5f, z, y);
+    float r = m + y;
+    r = fmaf(0.693359375f, fe, r);
+    return r;
+}
+
+SRD float pow_pinned(float x, float y) { return exp_pinned(y * log_pinned(x)); }
+
 // binary16 conversions: v_cvt_f16_f32 / v_cvt_f32_f16 (round-to-nearest-even, denormals kept)
 SRD uint32_t f32_to_f16_bits(float f) { return (uint32_t)__half_as_ushort(__float2half_rn(f)); }
 SRD float f16_bits_to_f32(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)(h & 0xFFFFu))); }
@@ -199,6 +233,15 @@ SRD uint32_t to_ufloat(float f) {
 SRD uint32_t pack_b10g11r11(float r, float g, float b) {
     return to_ufloat<6>(r) | (to_ufloat<6>(g) << 11) | (to_ufloat<5>(b) << 22);
 }
+
+template <int MANT>
+SRD float from_ufloat(uint32_t v) {
+    const uint32_t e = v >> MANT, m = v & ((1u << MANT) - 1u);
+    if (e == 0u) return (float)m * __uint_as_float((uint32_t)(127 - 14 - MANT) << 23);
+    if (e == 31u) return __uint_as_float(0x7f800000u | (m << (23 - MANT)));
+    return __uint_as_float(((e + 112u) << 23) | (m << (23 - MANT)));
+}
+SRD f3 unpack_b10g11r11(uint32_t v) { return mk3(from_ufloat<6>(v & 0x7ffu), from_ufloat<6>((v >> 11) & 0x7ffu), from_ufloat<5>(v >> 22)); }
 
 // ---- rt_utils.slang:150-234 BRDF helpers ------------------------------------------------------
 SRD void build_onb(f3 n, f3& t, f3& b) {

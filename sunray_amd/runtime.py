@@ -99,6 +99,10 @@ class DeviceFrame:
         self.motion = z(n, dtype=torch.int32)      # R16G16_SFLOAT
         self.reservoirs = [z(n, 12, dtype=torch.int32), z(n, 12, dtype=torch.int32)]      # 48 B records
         self.reservoirs_gi = [z(n, 12, dtype=torch.int32), z(n, 12, dtype=torch.int32)]
+        # post-RT chain images (B10G11R11 ping-pongs, RGBA8 output)
+        self.accum = [z(n, dtype=torch.int32), z(n, dtype=torch.int32)]
+        self.denoise = [z(n, dtype=torch.int32), z(n, dtype=torch.int32)]
+        self.output = z(n, dtype=torch.int32)
         bn = np.ascontiguousarray(blue_noise, dtype=np.uint8)
         self.blue_noise_shape = bn.shape[:2]
         self.blue_noise = torch.from_numpy(bn.copy()).to(self.device)
@@ -113,6 +117,9 @@ class DeviceFrame:
             "motion": self.motion.cpu().numpy().view(np.uint32),
             "reservoirs": [r.cpu().numpy().view(np.uint32).reshape(-1).view(abi.RESERVOIR) for r in self.reservoirs],
             "reservoirs_gi": [r.cpu().numpy().view(np.uint32).reshape(-1).view(abi.RESERVOIR_GI) for r in self.reservoirs_gi],
+            "accum": [a.cpu().numpy().view(np.uint32) for a in self.accum],
+            "denoise": [a.cpu().numpy().view(np.uint32) for a in self.denoise],
+            "output": self.output.cpu().numpy().view(np.uint32),
         }
         return out
 
@@ -257,6 +264,19 @@ class Scene:
         ms, n = C.c_double(), C.c_uint32()
         check(lib().sr_scene_read_timing(self._h, C.c_int(kind), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def post_chain(frame, frame_count, exposure=1.0, denoise_passes=4):
+    """temporal_accumulation -> denoise_0..N-1 -> postprocess on the current stream (lib.rs:1576-1615)."""
+    p = abi.post_params(frame, frame_count, lambda t: t.data_ptr(), exposure, denoise_passes)
+    check(lib().sr_post_temporal(C.byref(p), _stream()))
+    check(lib().sr_post_denoise(C.byref(p), _stream()))
+    check(lib().sr_post_tonemap(C.byref(p), _stream()))
 
 
 def rays_to_device(rays_np, device="cuda:0"):

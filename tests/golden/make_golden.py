@@ -20,6 +20,10 @@ CASES = {
     "cornell_glass_mirror": (scenes.cornell_glass_mirror, 48, 48, 2, None),
     "cornell_box_norestir": (scenes.cornell_box, 48, 48, 2, dict(enable_restir=0, max_bounces=3, shadow_bounces=3)),
 }
+# full frames incl. the post-RT compute chain (temporal accumulation -> 4x a-trous -> tonemap), RGBA8 output
+POST_CASES = {
+    "cornell_glass_mirror_post": (scenes.cornell_glass_mirror, 40, 40, 6),
+}
 
 
 def make_config(over):
@@ -54,7 +58,29 @@ def render(name):
     return out
 
 
+def render_post(name):
+    fn, W, H, frames = POST_CASES[name]
+    desc = fn()
+    s = ob.OracleScene().load(desc)
+    fr = ob.HostFrame(W, H, scenes.white_noise_rgba8())
+    prev, out = None, {}
+    for f in range(frames):
+        m = ob.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, prev)
+        prev = list(m.view_proj)
+        s.trace_ris(fr, m, f)
+        s.trace_final(fr, m, f)
+        ob.post_chain(fr, f)
+        if f >= frames - 3:   # temporal accumulation only blends history from frame_count > 2 on
+            out["f%d_accum" % f] = fr.accum[f % 2].copy()
+            out["f%d_denoise" % f] = fr.denoise[1].copy()
+            out["f%d_output" % f] = fr.output.copy()
+    return out
+
+
 if __name__ == "__main__":
+    for name in POST_CASES:
+        np.savez_compressed(os.path.join(HERE, "pass_%s.npz" % name), **render_post(name))
+        print("wrote", name)
     for name in CASES:
         np.savez_compressed(os.path.join(HERE, "pass_%s.npz" % name), **render(name))
         print("wrote", name)

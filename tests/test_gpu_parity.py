@@ -278,6 +278,67 @@ def test_error_behaviour(rt, blue_noise):
     assert e.value.code == -5
 
 
+# ---- post-RT compute chain --------------------------------------------------------
+@pytest.mark.parametrize("name", list(make_golden.POST_CASES))
+def test_post_chain_matches_committed_golden(rt, name, blue_noise):
+    fn, W, H, frames = make_golden.POST_CASES[name]
+    want = np.load(os.path.join(GOLDEN, "pass_%s.npz" % name))
+    desc = fn()
+    gsc = rt.Scene(0).load(desc)
+    gf = rt.DeviceFrame(W, H, blue_noise)
+    prev = None
+    for f in range(frames):
+        m = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, prev)
+        prev = list(m.view_proj)
+        gsc.trace_ris(gf, m, f); gsc.trace_final(gf, m, f)
+        rt.post_chain(gf, f)
+        if f >= frames - 3:
+            h = gf.host()
+            assert_bits_equal(want["f%d_accum" % f], h["accum"][f % 2], "accum f%d" % f)
+            assert_bits_equal(want["f%d_denoise" % f], h["denoise"][1], "denoise f%d" % f)
+            assert_bits_equal(want["f%d_output" % f], h["output"], "RGBA8 output f%d" % f)
+
+
+@pytest.mark.parametrize("scene_fn,W,H,frames", [
+    (scenes.cornell_box, 200, 152, 6),                      # ragged extent; temporal history active from frame 3
+    (lambda: scenes.heightfield(n=300), 320, 180, 5),
+])
+def test_full_frames_with_post_chain_equal_oracle(rt, oracle, blue_noise, scene_fn, W, H, frames):
+    desc = scene_fn()
+    osc, gsc = oracle.OracleScene().load(desc), rt.Scene(0).load(desc)
+    of, gf = oracle.HostFrame(W, H, blue_noise), rt.DeviceFrame(W, H, blue_noise)
+    prev = None
+    for f in range(frames):
+        pos = (desc.camera_pos[0] + 0.02 * f, desc.camera_pos[1], desc.camera_pos[2])   # slow dolly: real reprojection
+        om = oracle.camera_matrices(pos, desc.camera_target, desc.fov_y, W, H, prev)
+        gm = rt.camera_matrices(pos, desc.camera_target, desc.fov_y, W, H, prev)
+        prev = list(om.view_proj)
+        osc.trace_ris(of, om, f); osc.trace_final(of, om, f); oracle.post_chain(of, f)
+        gsc.trace_ris(gf, gm, f); gsc.trace_final(gf, gm, f); rt.post_chain(gf, f)
+        h = gf.host()
+        assert_bits_equal(of.accum[f % 2], h["accum"][f % 2], "accum f%d" % f)
+        assert_bits_equal(of.denoise[0], h["denoise"][0], "denoise a f%d" % f)
+        assert_bits_equal(of.denoise[1], h["denoise"][1], "denoise b f%d" % f)
+        assert_bits_equal(of.output, h["output"], "RGBA8 output f%d" % f)
+    rgba = h["output"].view(np.uint8).reshape(-1, 4)
+    assert (rgba[:, 3] == 255).all() and rgba[:, :3].any()
+
+
+def test_post_chain_error_behaviour(rt, blue_noise):
+    import ctypes as C
+    from sunray_amd._lib import lib
+    gf = rt.DeviceFrame(16, 16, blue_noise)
+    p = abi.post_params(gf, 0, lambda t: t.data_ptr())
+    p.accum[1] = None
+    assert lib().sr_post_temporal(C.byref(p), None) == -1 and b"ping-pong" in lib().sr_last_error()
+    p = abi.post_params(gf, 0, lambda t: t.data_ptr())
+    p.denoise_passes = 0
+    assert lib().sr_post_denoise(C.byref(p), None) == -1
+    p = abi.post_params(gf, 0, lambda t: t.data_ptr())
+    p.output_rgba8 = None
+    assert lib().sr_post_tonemap(C.byref(p), None) == -1
+
+
 # ---- BASELINE.json full sizes ---------------------------------------------------------------------
 def test_full_size_1m_triangles_1080p(rt, oracle, blue_noise):
     """The bench workload itself (1920x1080, 999 714 triangles, reference constants): the oracle is fast
