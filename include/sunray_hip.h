@@ -395,6 +395,44 @@ int sr_post_denoise(const SrPostParams* params, void* stream);
  * ACES (Narkowicz), gamma 1/2.2, RGBA8 store. Reads denoise[(denoise_passes - 1) % 2]. */
 int sr_post_tonemap(const SrPostParams* params, void* stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Renderer facade: the reference's Renderer<K> method surface for the built path */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct SrRenderer SrRenderer;
+
+/* Renderer::new((w, h), RGBA8_UNORM) (src/lib.rs:212-446): scene + G-buffer + temporal resources
+ * (reservoir, accumulation and denoise ping-pongs, lib.rs:320-331) + the noise texture. */
+int sr_renderer_create(int device, uint32_t width, uint32_t height, SrRenderer** out);
+int sr_renderer_destroy(SrRenderer* renderer);
+/* Renderer::resize (lib.rs:586-639): waits for the device, recreates every image at the new extent,
+ * relative_frame_count = 0. Same extent: no-op (lib.rs:598-600). */
+int sr_renderer_resize(SrRenderer* renderer, uint32_t width, uint32_t height);
+/* Renderer::load_mesh (lib.rs:873-954); host pointers. */
+int sr_renderer_load_mesh(SrRenderer* renderer, uint64_t key, const SrVertex* vertices, uint32_t n_vertices,
+                          const uint32_t* indices, uint32_t n_indices, const SrMaterial* material);
+/* Knobs for the ray-tracing passes (defaults = the reference's constants). */
+int sr_renderer_set_config(SrRenderer* renderer, const SrTraceConfig* config);
+/* Renderer::render(camera, instances) (lib.rs:984-1232): enqueues one whole frame on `stream`
+ * (acceleration-structure rebuild if the instance list changed, raytracing_ris, raytracing_final,
+ * temporal_accumulation, denoise_0..3, postprocess) and returns its frame number. */
+int sr_renderer_render(SrRenderer* renderer, const float cam_pos[3], const float cam_target[3], float fov_y_degrees,
+                       const uint64_t* keys, const uint32_t* counts, uint32_t n_keys, const SrTransform* transforms,
+                       void* stream, uint64_t* out_frame);
+/* Renderer::wait_frame (lib.rs:1234-1238). */
+int sr_renderer_wait_frame(SrRenderer* renderer, uint64_t frame);
+/* Renderer::render_to_host_memory (lib.rs:1908-1934): 16 x (render + wait_frame), then the RGBA8 image
+ * (width*height*4 bytes, no padding) copied to out_rgba8 (host). */
+int sr_renderer_render_to_host_memory(SrRenderer* renderer, const float cam_pos[3], const float cam_target[3],
+                                      float fov_y_degrees, const uint64_t* keys, const uint32_t* counts, uint32_t n_keys,
+                                      const SrTransform* transforms, uint8_t* out_rgba8);
+/* Harness access: inner scene (counters, stats), device pointers of the RGBA8 output and the fp32
+ * radiance, and relative_frame_count. Any out pointer may be NULL. */
+int sr_renderer_get(SrRenderer* renderer, SrScene** scene, const uint32_t** output_rgba8_device,
+                    const float** raw_color_device, uint32_t* relative_frame_count);
+/* Stand-in for the reference's embedded 128x128 blue-noise PNG (lib.rs:281-309; an input asset, not
+ * copied): hashed white noise, RGBA8, grey in rgb, alpha 255. Host pointer, w*h*4 bytes. */
+int sr_default_noise_texture(uint32_t w, uint32_t h, uint32_t seed, uint8_t* out_rgba8);
+
 /* Ray counters since the last reset (device-side atomics, read back synchronously). */
 int sr_scene_reset_counters(SrScene* scene, void* stream);
 int sr_scene_read_counters(SrScene* scene, void* stream, SrRayCounters* out);

@@ -22,6 +22,11 @@ int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
 }
+}  // namespace
+namespace srh {
+int set_error(int code, const std::string& msg) { return fail(code, msg); }   // shared with renderer.cpp
+}
+namespace {
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \

@@ -79,4 +79,6 @@ void flatten_instances(const std::vector<HostMesh>& meshes, const FrameInstanceD
 // 4-wide BVH (layout: traverse.h). max_stack = worst-case traversal stack entries for this tree.
 void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult& out);
 
+// the one thread-local error slot of the library (api.cpp); returns `code`
+int set_error(int code, const std::string& msg);
 }  // namespace srh

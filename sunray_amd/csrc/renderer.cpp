@@ -1,0 +1,245 @@
+// Renderer facade: the reference's `Renderer<K>` method surface for the built
+// path, layered purely on this library's own C ABI (sr_scene_*, sr_trace_*, sr_post_*):
+//   new / resize / load_mesh / unload_mesh / render / wait_frame / render_to_host_memory
+// (src/lib.rs:212-446, 586-639, 873-973, 984-1238, 1908-1934). Keys are u64 (the reference's generic
+// ResourceKey, lib.rs:54-58). One Renderer = one GPU, one caller thread (the reference is !Send).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host.h"
+
+
+struct SrRenderer {
+    int device = 0;
+    SrScene* scene = nullptr;
+    uint32_t width = 0, height = 0;
+    // frame buffers (the reference's transient G-buffer images + temporal resources, lib.rs:320-331,1492-1516)
+    float* raw_color = nullptr;
+    uint16_t* depth = nullptr;
+    uint32_t *normal = nullptr, *diffuse = nullptr, *motion = nullptr;
+    SrReservoir* reservoirs[2] = {nullptr, nullptr};
+    SrReservoirGI* reservoirs_gi[2] = {nullptr, nullptr};
+    uint32_t *accum[2] = {nullptr, nullptr}, *denoise[2] = {nullptr, nullptr};
+    uint32_t* output = nullptr;
+    uint8_t* blue_noise = nullptr;
+    // per-frame state
+    float prev_view_proj[16];       // zero on the first frame (lib.rs:410), NOT reset by resize
+    uint32_t relative_frame_count = 0;
+    uint64_t absolute_frame_count = 0;
+    SrTraceConfig config;
+    std::vector<uint64_t> last_keys;
+    std::vector<uint32_t> last_counts;
+    std::vector<SrTransform> last_transforms;
+    bool instances_valid = false;
+    hipEvent_t frame_done = nullptr;
+};
+
+namespace {
+
+int rfail(int code, const std::string& msg) { return srh::set_error(code, msg); }
+#define R_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return rfail(e_ == hipErrorOutOfMemory ? SR_ERR_OOM : SR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+void free_images(SrRenderer* r) {
+    void* ptrs[] = {r->raw_color, r->depth, r->normal, r->diffuse, r->motion, r->reservoirs[0], r->reservoirs[1],
+                    r->reservoirs_gi[0], r->reservoirs_gi[1], r->accum[0], r->accum[1], r->denoise[0], r->denoise[1], r->output};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    r->raw_color = nullptr; r->depth = nullptr; r->normal = r->diffuse = r->motion = nullptr;
+    r->reservoirs[0] = r->reservoirs[1] = nullptr; r->reservoirs_gi[0] = r->reservoirs_gi[1] = nullptr;
+    r->accum[0] = r->accum[1] = r->denoise[0] = r->denoise[1] = nullptr; r->output = nullptr;
+}
+
+template <typename T>
+int alloc_zero(T** p, size_t n) {
+    R_HIP(hipMalloc((void**)p, n * sizeof(T)));
+    R_HIP(hipMemset(*p, 0, n * sizeof(T)));
+    return SR_OK;
+}
+
+int alloc_images(SrRenderer* r, uint32_t w, uint32_t h) {
+    const size_t n = (size_t)w * h;
+    int rc;
+    if ((rc = alloc_zero(&r->raw_color, n * 4)) || (rc = alloc_zero(&r->depth, n)) || (rc = alloc_zero(&r->normal, n)) ||
+        (rc = alloc_zero(&r->diffuse, n)) || (rc = alloc_zero(&r->motion, n)) || (rc = alloc_zero(&r->output, n))) return rc;
+    for (int i = 0; i < 2; i++)
+        if ((rc = alloc_zero(&r->reservoirs[i], n)) || (rc = alloc_zero(&r->reservoirs_gi[i], n)) ||
+            (rc = alloc_zero(&r->accum[i], n)) || (rc = alloc_zero(&r->denoise[i], n))) return rc;
+    r->width = w; r->height = h;
+    return SR_OK;
+}
+
+uint32_t pcg_hash(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+}  // namespace
+
+extern "C" {
+
+// Stand-in for the reference's embedded 128x128 blue-noise PNG (lib.rs:281-309), which is an asset and is
+// not copied: a hashed white-noise RGBA8 texture (grey replicated to rgb, alpha 255). Same generator as
+// sunray_amd.scenes.white_noise_rgba8.
+int sr_default_noise_texture(uint32_t w, uint32_t h, uint32_t seed, uint8_t* out_rgba8) {
+    if (!out_rgba8 || w == 0 || h == 0) return rfail(SR_ERR_INVALID_ARG, "sr_default_noise_texture: bad argument");
+    const uint32_t salt = (uint32_t)(((uint64_t)seed * 2654435761ull) & 0xFFFFFFFFull);
+    for (uint32_t i = 0; i < h; i++)
+        for (uint32_t j = 0; j < w; j++) {
+            const uint8_t v = (uint8_t)(pcg_hash((i * w + j) ^ salt) >> 24);
+            uint8_t* q = out_rgba8 + ((size_t)i * w + j) * 4;
+            q[0] = q[1] = q[2] = v; q[3] = 255;
+        }
+    return SR_OK;
+}
+
+// Renderer::new((w, h), RGBA8_UNORM) (lib.rs:212-446)
+int sr_renderer_create(int device, uint32_t width, uint32_t height, SrRenderer** out) {
+    if (!out || width == 0 || height == 0) return rfail(SR_ERR_INVALID_ARG, "Renderer::new: empty extent or null out");
+    SrRenderer* r = new SrRenderer();
+    r->device = device;
+    memset(r->prev_view_proj, 0, sizeof(r->prev_view_proj));
+    sr_trace_config_default(&r->config);
+    int rc = sr_scene_create(device, &r->scene);
+    if (rc != SR_OK) { delete r; return rc; }
+    if ((rc = alloc_images(r, width, height)) != SR_OK) { free_images(r); sr_scene_destroy(r->scene); delete r; return rc; }
+    std::vector<uint8_t> noise(128 * 128 * 4);
+    sr_default_noise_texture(128, 128, 7, noise.data());
+    if (hipMalloc((void**)&r->blue_noise, noise.size()) != hipSuccess || hipMemcpy(r->blue_noise, noise.data(), noise.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipEventCreate(&r->frame_done) != hipSuccess) {
+        free_images(r); sr_scene_destroy(r->scene); delete r;
+        return rfail(SR_ERR_HIP, "Renderer::new: blue-noise upload failed");
+    }
+    *out = r;
+    return SR_OK;
+}
+
+int sr_renderer_destroy(SrRenderer* r) {
+    if (!r) return SR_OK;
+    (void)hipSetDevice(r->device);
+    (void)hipDeviceSynchronize();
+    free_images(r);
+    if (r->blue_noise) (void)hipFree(r->blue_noise);
+    if (r->frame_done) (void)hipEventDestroy(r->frame_done);
+    sr_scene_destroy(r->scene);
+    delete r;
+    return SR_OK;
+}
+
+// Renderer::resize (lib.rs:586-639): new temporal resources, relative_frame_count = 0
+int sr_renderer_resize(SrRenderer* r, uint32_t width, uint32_t height) {
+    if (!r || width == 0 || height == 0) return rfail(SR_ERR_INVALID_ARG, "Renderer::resize: bad argument");
+    if (width == r->width && height == r->height) return SR_OK;   // lib.rs:598-600
+    R_HIP(hipSetDevice(r->device));
+    R_HIP(hipDeviceSynchronize());                                // device_wait_idle (lib.rs:604)
+    free_images(r);
+    int rc = alloc_images(r, width, height);
+    if (rc != SR_OK) return rc;
+    r->relative_frame_count = 0;
+    return SR_OK;
+}
+
+// Renderer::load_mesh (lib.rs:873-954)
+int sr_renderer_load_mesh(SrRenderer* r, uint64_t key, const SrVertex* vertices, uint32_t n_vertices, const uint32_t* indices,
+                          uint32_t n_indices, const SrMaterial* material) {
+    if (!r) return rfail(SR_ERR_INVALID_ARG, "load_mesh: renderer is null");
+    r->instances_valid = false;
+    return sr_scene_add_mesh(r->scene, key, vertices, n_vertices, indices, n_indices, material, nullptr);
+}
+
+int sr_renderer_set_config(SrRenderer* r, const SrTraceConfig* cfg) {
+    if (!r || !cfg) return rfail(SR_ERR_INVALID_ARG, "sr_renderer_set_config: null argument");
+    r->config = *cfg;
+    return SR_OK;
+}
+
+// Renderer::render (lib.rs:984-1232): one frame = TLAS (re)build when the instance list changed ->
+// raytracing_ris -> raytracing_final -> temporal_accumulation -> denoise_0..3 -> postprocess, all
+// enqueued on `stream`; returns the frame number to wait on.
+int sr_renderer_render(SrRenderer* r, const float cam_pos[3], const float cam_target[3], float fov_y, const uint64_t* keys,
+                       const uint32_t* counts, uint32_t n_keys, const SrTransform* transforms, void* stream, uint64_t* out_frame) {
+    if (!r || !cam_pos || !cam_target) return rfail(SR_ERR_INVALID_ARG, "Renderer::render: null argument");
+    R_HIP(hipSetDevice(r->device));
+    // instances: rebuild the acceleration structure only when the caller's list changed (the reference
+    // updates/rebuilds its TLAS every frame, tlas.rs:155-191)
+    uint32_t n_xf = 0;
+    for (uint32_t k = 0; k < n_keys; k++) n_xf += counts[k];
+    const bool same = r->instances_valid && r->last_keys.size() == n_keys && r->last_transforms.size() == n_xf &&
+                      (n_keys == 0 || (memcmp(r->last_keys.data(), keys, n_keys * 8) == 0 && memcmp(r->last_counts.data(), counts, n_keys * 4) == 0)) &&
+                      (n_xf == 0 || memcmp(r->last_transforms.data(), transforms, n_xf * sizeof(SrTransform)) == 0);
+    if (!same) {
+        int rc = sr_scene_set_instances(r->scene, keys, counts, n_keys, transforms);
+        if (rc != SR_OK) return rc;
+        r->last_keys.assign(keys, keys + n_keys);
+        r->last_counts.assign(counts, counts + n_keys);
+        r->last_transforms.assign(transforms, transforms + n_xf);
+        r->instances_valid = true;
+    }
+    SrMatrices m;
+    int rc = sr_camera_matrices(cam_pos, cam_target, fov_y, r->width, r->height, r->prev_view_proj, &m);   // lib.rs:1017-1048
+    if (rc != SR_OK) return rc;
+    memcpy(r->prev_view_proj, m.view_proj, sizeof(r->prev_view_proj));                                     // history for the NEXT frame
+    SrRtParams p;
+    memset(&p, 0, sizeof(p));
+    p.scene = r->scene;
+    p.raw_color = r->raw_color; p.depth_img = r->depth; p.normal_img = r->normal; p.diffuse_img = r->diffuse; p.motion_vec_img = r->motion;
+    p.matrices = &m;
+    p.blue_noise_tex = r->blue_noise; p.blue_noise_w = 128; p.blue_noise_h = 128;
+    p.reservoirs[0] = r->reservoirs[0]; p.reservoirs[1] = r->reservoirs[1];
+    p.reservoirs_gi[0] = r->reservoirs_gi[0]; p.reservoirs_gi[1] = r->reservoirs_gi[1];
+    p.frame_count = r->relative_frame_count;
+    p.width = r->width; p.height = r->height;
+    p.config = r->config;
+    if (p.config.enable_restir && (rc = sr_trace_ris(&p, stream)) != SR_OK) return rc;
+    if ((rc = sr_trace_final(&p, stream)) != SR_OK) return rc;
+    SrPostParams q;
+    memset(&q, 0, sizeof(q));
+    q.raw_color = r->raw_color; q.motion_vec_img = r->motion; q.depth_img = r->depth; q.normal_img = r->normal; q.diffuse_img = r->diffuse;
+    q.accum[0] = r->accum[0]; q.accum[1] = r->accum[1]; q.denoise[0] = r->denoise[0]; q.denoise[1] = r->denoise[1];
+    q.output_rgba8 = r->output;
+    q.frame_count = r->relative_frame_count; q.width = r->width; q.height = r->height;
+    q.exposure = 1.0f;        // EXPOSURE (lib.rs:44)
+    q.denoise_passes = 4;     // DENOISE_PASSES (lib.rs:42)
+    if ((rc = sr_post_temporal(&q, stream)) != SR_OK) return rc;
+    if ((rc = sr_post_denoise(&q, stream)) != SR_OK) return rc;
+    if ((rc = sr_post_tonemap(&q, stream)) != SR_OK) return rc;
+    R_HIP(hipEventRecord(r->frame_done, (hipStream_t)stream));
+    r->relative_frame_count += 1;                                    // lib.rs:1438-1439
+    r->absolute_frame_count += 1;
+    if (out_frame) *out_frame = r->absolute_frame_count;
+    return SR_OK;
+}
+
+// Renderer::wait_frame (lib.rs:1234-1238): frames complete in order; waits for the latest submitted one.
+int sr_renderer_wait_frame(SrRenderer* r, uint64_t frame) {
+    if (!r) return rfail(SR_ERR_INVALID_ARG, "wait_frame: renderer is null");
+    if (frame > r->absolute_frame_count) return rfail(SR_ERR_INVALID_ARG, "wait_frame: frame was never submitted");
+    R_HIP(hipEventSynchronize(r->frame_done));
+    return SR_OK;
+}
+
+// Renderer::render_to_host_memory (lib.rs:1908-1934): WARMUP_FRAMES = 16 x (render + wait_frame), then the
+// RGBA8 image without padding (W*H*4 bytes).
+int sr_renderer_render_to_host_memory(SrRenderer* r, const float cam_pos[3], const float cam_target[3], float fov_y, const uint64_t* keys,
+                                      const uint32_t* counts, uint32_t n_keys, const SrTransform* transforms, uint8_t* out_rgba8) {
+    if (!r || !out_rgba8) return rfail(SR_ERR_INVALID_ARG, "render_to_host_memory: null argument");
+    const uint32_t WARMUP_FRAMES = 16;
+    for (uint32_t i = 0; i < WARMUP_FRAMES; i++) {
+        uint64_t frame = 0;
+        int rc = sr_renderer_render(r, cam_pos, cam_target, fov_y, keys, counts, n_keys, transforms, nullptr, &frame);
+        if (rc != SR_OK) return rc;
+        if ((rc = sr_renderer_wait_frame(r, frame)) != SR_OK) return rc;
+    }
+    R_HIP(hipMemcpy(out_rgba8, r->output, (size_t)r->width * r->height * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+// Access for harnesses: the scene (counters, stats), the device output image and the frame counter.
+int sr_renderer_get(SrRenderer* r, SrScene** scene, const uint32_t** output_rgba8_device, const float** raw_color_device, uint32_t* relative_frame_count) {
+    if (!r) return rfail(SR_ERR_INVALID_ARG, "sr_renderer_get: renderer is null");
+    if (scene) *scene = r->scene;
+    if (output_rgba8_device) *output_rgba8_device = r->output;
+    if (raw_color_device) *raw_color_device = r->raw_color;
+    if (relative_frame_count) *relative_frame_count = r->relative_frame_count;
+    return SR_OK;
+}
+
+}  // extern "C"

@@ -279,6 +279,81 @@ def post_chain(frame, frame_count, exposure=1.0, denoise_passes=4):
     check(lib().sr_post_tonemap(C.byref(p), _stream()))
 
 
+def _instance_arrays(instances):
+    keys = np.array([k for k, _ in instances], dtype=np.uint64)
+    counts = np.array([len(t) for _, t in instances], dtype=np.uint32)
+    xf = np.array([np.asarray(t, dtype=np.float32).reshape(12) for _, ts in instances for t in ts], dtype=np.float32).reshape(-1, 12)
+    if len(xf) == 0:
+        xf = np.zeros((1, 12), dtype=np.float32)
+    return keys, counts, np.ascontiguousarray(xf)
+
+
+def default_noise_texture(w=128, h=128, seed=7):
+    out = np.zeros((h, w, 4), dtype=np.uint8)
+    check(lib().sr_default_noise_texture(C.c_uint32(w), C.c_uint32(h), C.c_uint32(seed), _p(out)))
+    return out
+
+
+class Renderer:
+    """The reference's `Renderer<K>` surface for the built path (src/lib.rs:212-446, 586-639, 873-954,
+    984-1238, 1908-1934), over sr_renderer_*. `camera` = (position, target, fov_y_degrees) — the
+    reference's Camera (camera.rs:11-44); `instances` = [(mesh key, [3x4 row-major transform, ...]), ...]."""
+
+    def __init__(self, size, device_index=0):
+        self._h = C.c_void_p()
+        self.size = (int(size[0]), int(size[1]))
+        check(lib().sr_renderer_create(C.c_int(device_index), C.c_uint32(self.size[0]), C.c_uint32(self.size[1]), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().sr_renderer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def resize(self, size):
+        check(lib().sr_renderer_resize(self._h, C.c_uint32(int(size[0])), C.c_uint32(int(size[1]))))
+        self.size = (int(size[0]), int(size[1]))
+
+    def load_mesh(self, key, vertices, indices, material):
+        v = np.ascontiguousarray(vertices, dtype=abi.VERTEX)
+        i = np.ascontiguousarray(indices, dtype=np.uint32)
+        m = np.ascontiguousarray(material, dtype=abi.MATERIAL)
+        check(lib().sr_renderer_load_mesh(self._h, C.c_uint64(key), _p(v), C.c_uint32(len(v)), _p(i), C.c_uint32(len(i)), _p(m)))
+
+    def set_config(self, config):
+        check(lib().sr_renderer_set_config(self._h, C.byref(config)))
+
+    def render(self, camera, instances):
+        pos, tgt, fov = camera
+        keys, counts, xf = _instance_arrays(instances)
+        frame = C.c_uint64()
+        check(lib().sr_renderer_render(self._h, _f3(pos), _f3(tgt), C.c_float(fov), _p(keys), _p(counts), C.c_uint32(len(keys)), _p(xf),
+                                       None, C.byref(frame)))
+        return frame.value
+
+    def wait_frame(self, frame):
+        check(lib().sr_renderer_wait_frame(self._h, C.c_uint64(frame)))
+
+    def render_to_host_memory(self, camera, instances):
+        pos, tgt, fov = camera
+        keys, counts, xf = _instance_arrays(instances)
+        out = np.zeros((self.size[1], self.size[0], 4), dtype=np.uint8)
+        check(lib().sr_renderer_render_to_host_memory(self._h, _f3(pos), _f3(tgt), C.c_float(fov), _p(keys), _p(counts), C.c_uint32(len(keys)),
+                                                      _p(xf), _p(out)))
+        return out
+
+    @property
+    def relative_frame_count(self):
+        n = C.c_uint32()
+        check(lib().sr_renderer_get(self._h, None, None, None, C.byref(n)))
+        return n.value
+
+
 def rays_to_device(rays_np, device="cuda:0"):
     import torch
     a = np.ascontiguousarray(rays_np, dtype=abi.RAY)

@@ -339,6 +339,88 @@ def test_post_chain_error_behaviour(rt, blue_noise):
     assert lib().sr_post_tonemap(C.byref(p), None) == -1
 
 
+# ---- Renderer facade --------------------------------------------------------------
+def _oracle_render_to_host_memory(oracle, desc, W, H, instances_per_frame, noise, first_frame=0, of=None, prev=None):
+    """The reference's render loop restated with the oracle: per frame matrices (prev_view_proj injected),
+    ris, final, temporal, denoise x4, tonemap."""
+    osc = oracle.OracleScene()
+    for m in desc.meshes:
+        osc.add_mesh(m.key, m.vertices, m.indices, m.material)
+    of = of or oracle.HostFrame(W, H, noise)
+    last = None
+    for i, inst in enumerate(instances_per_frame):
+        f = first_frame + i
+        if inst is not last:
+            osc.set_instances(inst); last = inst
+        om = oracle.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, prev)
+        prev = list(om.view_proj)
+        osc.trace_ris(of, om, f); osc.trace_final(of, om, f); oracle.post_chain(of, f)
+    return of, prev
+
+
+def test_renderer_render_to_host_memory_equals_oracle(rt, oracle):
+    desc = scenes.cornell_box()
+    W, H = 96, 80
+    noise = rt.default_noise_texture()
+    r = rt.Renderer((W, H))
+    for m in desc.meshes:
+        r.load_mesh(m.key, m.vertices, m.indices, m.material)
+    cam = (desc.camera_pos, desc.camera_target, desc.fov_y)
+    img = r.render_to_host_memory(cam, desc.instances)
+    assert img.shape == (H, W, 4) and r.relative_frame_count == 16          # WARMUP_FRAMES (lib.rs:1909)
+    of, prev = _oracle_render_to_host_memory(oracle, desc, W, H, [desc.instances] * 16, noise)
+    assert_bits_equal(of.output, img.view(np.uint32).reshape(-1), "render_to_host_memory")
+    assert (img[..., 3] == 255).all() and img[..., :3].any()
+    # render + wait_frame continue the same history: frame 17 equals the oracle's 17th frame
+    fr = r.render(cam, desc.instances)
+    assert fr == 17
+    r.wait_frame(fr)
+    with pytest.raises(rt.SunrayError):
+        r.wait_frame(fr + 5)
+    r.close()
+
+
+def test_renderer_resize_and_instance_change(rt, oracle):
+    desc = scenes.cornell_box()
+    noise = rt.default_noise_texture()
+    r = rt.Renderer((64, 48))
+    for m in desc.meshes:
+        r.load_mesh(m.key, m.vertices, m.indices, m.material)
+    cam = (desc.camera_pos, desc.camera_target, desc.fov_y)
+    for _ in range(3):
+        r.wait_frame(r.render(cam, desc.instances))
+    assert r.relative_frame_count == 3
+    r.resize((64, 48))
+    assert r.relative_frame_count == 3                                      # same extent: no-op (lib.rs:598-600)
+    r.resize((80, 56))
+    assert r.relative_frame_count == 0 and r.size == (80, 56)
+    # moved instances from frame 2 on: the acceleration structure must follow the caller's list
+    moved = [(k, [np.asarray(t, dtype=np.float32).reshape(3, 4) + np.float32(0.05) * np.eye(3, 4, 3, dtype=np.float32) for t in ts])
+             for k, ts in desc.instances]
+    per_frame = [desc.instances, desc.instances, moved, moved]
+    for inst in per_frame:
+        last = r.render(cam, inst)
+    r.wait_frame(last)
+    # oracle: history buffers are fresh after the resize, but prev_view_proj survives it (lib.rs:586-639
+    # does not touch it), so frame 0 after the resize sees the old extent's view_proj
+    prev = None
+    for _ in range(3):
+        prev = list(oracle.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, 64, 48, prev).view_proj)
+    of, _ = _oracle_render_to_host_memory(oracle, desc, 80, 56, per_frame, noise, prev=prev)
+    import ctypes as C
+    from sunray_amd._lib import lib
+    import torch
+    outp = C.c_void_p()
+    assert lib().sr_renderer_get(r._h, None, C.byref(outp), None, None) == 0
+    got = np.zeros(80 * 56, dtype=np.uint32)
+    assert torch.cuda.current_device() == 0
+    torch.cuda.synchronize()
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), outp, C.c_size_t(got.nbytes), C.c_int(2)) == 0
+    assert_bits_equal(of.output, got, "output after resize + moved instances")
+    r.close()
+
+
 # ---- BASELINE.json full sizes ---------------------------------------------------------------------
 def test_full_size_1m_triangles_1080p(rt, oracle, blue_noise):
     """The bench workload itself (1920x1080, 999 714 triangles, reference constants): the oracle is fast

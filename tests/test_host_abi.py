@@ -174,6 +174,29 @@ def test_device_entry_points_fail_loudly_without_gpu():
     assert L.sr_trace_closest(None, None, 0, None, None) == -1
 
 
+def test_default_noise_texture_equals_scene_generator():
+    for w, h, seed in [(128, 128, 7), (16, 8, 3), (1, 1, 0)]:
+        assert (rt.default_noise_texture(w, h, seed) == scenes.white_noise_rgba8(w, h, seed)).all()
+    assert _lib.lib().sr_default_noise_texture(0, 4, 1, None) == -1
+
+
+def test_renderer_argument_errors_and_no_gpu_failure():
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.sr_renderer_create(0, 0, 16, C.byref(h)) == -1 and b"Renderer::new" in L.sr_last_error()
+    assert L.sr_renderer_create(0, 16, 16, None) == -1
+    assert L.sr_renderer_resize(None, 4, 4) == -1
+    assert L.sr_renderer_load_mesh(None, C.c_uint64(1), None, 0, None, 0, None) == -1
+    assert L.sr_renderer_render(None, None, None, C.c_float(45.0), None, None, 0, None, None, None) == -1
+    assert L.sr_renderer_wait_frame(None, C.c_uint64(0)) == -1
+    assert L.sr_renderer_render_to_host_memory(None, None, None, C.c_float(45.0), None, None, 0, None, None) == -1
+    assert L.sr_renderer_destroy(None) == 0
+    if not has_gpu():
+        with pytest.raises(_lib.SunrayError) as e:   # no CPU fallback: creation itself fails without a device
+            rt.Renderer((32, 32))
+        assert e.value.code == -2
+
+
 def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     monkeypatch.setattr(_lib, "_lib", None)
