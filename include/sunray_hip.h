@@ -101,6 +101,20 @@ typedef struct SrEmissiveIndirectionEntry {
     uint32_t entity_id;      /* instance index into the transform table */
 } SrEmissiveIndirectionEntry;
 
+/* Sampler parameters the path can observe (image/sampler.rs:14-22,77-94; scene.rs:68-83). The
+ * enumerators are VkFilter / VkSamplerAddressMode values. Every texture has ONE mip level and the
+ * shaders call SampleLevel(.., 0) with min_lod = max_lod = 0 (rt_utils.slang:121-133), so the
+ * MAGNIFICATION filter is the one applied; min_filter is carried for completeness only. — 16 B */
+#define SR_FILTER_NEAREST 0u
+#define SR_FILTER_LINEAR 1u
+#define SR_ADDRESS_REPEAT 0u
+#define SR_ADDRESS_MIRRORED_REPEAT 1u
+#define SR_ADDRESS_CLAMP_TO_EDGE 2u
+typedef struct SrSamplerDesc {
+    uint32_t min_filter, mag_filter;
+    uint32_t address_mode_u, address_mode_v;
+} SrSamplerDesc;
+
 /* T5  EntityTransform (rt_types.slang:101-103) = VkTransformMatrixKHR, row-major 3x4 (utils.rs:67-74) — 48 B */
 typedef struct SrTransform {
     float m[12];
@@ -283,6 +297,13 @@ int sr_scene_add_mesh(SrScene* scene, uint64_t key, const SrVertex* vertices, ui
                       const uint32_t* indices, uint32_t n_indices, const SrMaterial* material,
                       uint32_t* out_slot);
 
+/* Image::new_from_data (image/mod.rs:82-111): `channels` = 1..4 bytes per texel; fewer than 4 are
+ * widened to R8G8B8A8_UNORM with the missing channels 0x00 (utils.rs:27-43), no sRGB decode. Host
+ * pointer, w*h*channels bytes. Returns the image slot materials refer to (Material::*_image). */
+int sr_scene_add_image(SrScene* scene, const uint8_t* data, uint32_t width, uint32_t height, uint32_t channels,
+                       uint32_t* out_image_slot);
+/* Sampler::new (image/sampler.rs:44-67). Returns the sampler slot (Material::*_sampler). */
+int sr_scene_add_sampler(SrScene* scene, const SrSamplerDesc* desc, uint32_t* out_sampler_slot);
 /* ResourceManager::frame_instance_data (resource_manager.rs:216-267) + the dummy-entry padding of
  * Renderer::render (lib.rs:1058-1081) + the TLAS build it queues (resource_manager.rs:346-363):
  * keys[i] is instanced counts[i] times with the next counts[i] row-major 3x4 transforms taken from

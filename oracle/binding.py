@@ -84,6 +84,12 @@ def _f3(v):
     return (C.c_float * 3)(*[float(x) for x in v])
 
 
+def unpack_normal(p):
+    out = (C.c_float * 3)()
+    lib().orc_unpack_normal(C.c_uint32(p), out)
+    return np.array(list(out), dtype=np.float32)
+
+
 class OracleScene:
     """Oracle counterpart of sunray_amd.Scene: same methods, numpy (host) buffers."""
 
@@ -111,6 +117,26 @@ class OracleScene:
             raise ValueError("oracle add_mesh rejected the mesh (same checks as Renderer::load_mesh, lib.rs:880-899)")
         return slot
 
+    def add_image(self, pixels):
+        a = np.ascontiguousarray(pixels, dtype=np.uint8)
+        ch = 1 if a.ndim == 2 else a.shape[2]
+        slot = lib().orc_scene_add_image(self._h, _p(a), C.c_uint32(a.shape[1]), C.c_uint32(a.shape[0]), C.c_uint32(ch))
+        if slot < 0:
+            raise ValueError("oracle add_image rejected the image")
+        return slot
+
+    def add_sampler(self, min_filter, mag_filter, address_mode_u, address_mode_v):
+        d = abi.SrSamplerDesc(min_filter, mag_filter, address_mode_u, address_mode_v)
+        slot = lib().orc_scene_add_sampler(self._h, C.byref(d))
+        if slot < 0:
+            raise ValueError("oracle add_sampler rejected the sampler")
+        return slot
+
+    def sample_texture(self, image, sampler, u, v, fallback=(0.0, 0.0, 0.0, 0.0)):
+        out = (C.c_float * 4)()
+        lib().orc_sample_texture(self._h, C.c_uint32(image), C.c_uint32(sampler), C.c_float(u), C.c_float(v), (C.c_float * 4)(*fallback), out)
+        return np.array(list(out), dtype=np.float32)
+
     def set_instances(self, instances):
         keys = np.array([k for k, _ in instances], dtype=np.uint64)
         counts = np.array([len(t) for _, t in instances], dtype=np.uint32)
@@ -122,6 +148,10 @@ class OracleScene:
             raise ValueError("frame_instance_data: instance references a BLAS key that was never loaded")
 
     def load(self, desc):
+        for img in desc.images:
+            self.add_image(img)
+        for smp in desc.samplers:
+            self.add_sampler(*smp)
         for m in desc.meshes:
             self.add_mesh(m.key, m.vertices, m.indices, m.material)
         self.set_instances(desc.instances)

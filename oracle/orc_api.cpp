@@ -19,6 +19,15 @@ void orc_scene_destroy(void* s) { delete (Scene*)s; }
 int orc_scene_add_mesh(void* s, uint64_t key, const SrVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const SrMaterial* m) {
     return ((Scene*)s)->add_mesh(key, v, nv, idx, ni, m);
 }
+int orc_scene_add_image(void* s, const uint8_t* data, uint32_t w, uint32_t h, uint32_t channels) {
+    return ((Scene*)s)->add_image(data, w, h, channels);
+}
+int orc_scene_add_sampler(void* s, const SrSamplerDesc* d) { return ((Scene*)s)->add_sampler(d); }
+// KAT hook: one texture fetch
+void orc_sample_texture(void* s, uint32_t image, uint32_t sampler, float u, float v, const float* fallback4, float* out4) {
+    V4 r = ((Scene*)s)->sample_texture(image, sampler, u, v, V4{fallback4[0], fallback4[1], fallback4[2], fallback4[3]});
+    out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w;
+}
 int orc_scene_set_instances(void* s, const uint64_t* keys, const uint32_t* counts, uint32_t n_keys, const SrTransform* xf) {
     return ((Scene*)s)->set_instances(keys, counts, n_keys, xf);
 }

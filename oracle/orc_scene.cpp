@@ -125,6 +125,9 @@ int Scene::add_mesh(uint64_t key, const SrVertex* v, uint32_t nv, const uint32_t
     if (slots.count(key)) return -1;                              // lib.rs:880-884
     if (nv == 0 || ni == 0 || (ni % 3) != 0) return -1;           // lib.rs:885-891
     for (uint32_t i = 0; i < ni; i++) if (idx[i] >= nv) return -1;  // lib.rs:892-899
+    const uint32_t* tex = &m->base_color_image;                   // five (image, sampler) pairs
+    for (int i = 0; i < 10; i += 2)
+        if (tex[i] != SR_NULL_TEXTURE && (tex[i] >= images.size() || tex[i + 1] >= samplers.size())) return -1;
     Mesh mesh;
     mesh.key = key;
     mesh.vertices.assign(v, v + nv);
@@ -147,6 +150,32 @@ int Scene::add_mesh(uint64_t key, const SrVertex* v, uint32_t nv, const uint32_t
     slots[key] = slot;
     meshes.push_back(std::move(mesh));
     return (int)slot;
+}
+
+// Image::new_from_data (image/mod.rs:82-111) with utils::realign_data (utils.rs:27-43): R8/RG8/RGB8
+// are widened to RGBA8 with 0x00 in the missing channels; UNORM, no sRGB decode.
+int Scene::add_image(const uint8_t* data, uint32_t w, uint32_t h, uint32_t channels) {
+    if (!data || w == 0 || h == 0 || channels < 1 || channels > 4) return -1;
+    Image img;
+    img.w = w; img.h = h;
+    img.rgba.resize((size_t)w * h);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        uint32_t p = 0;
+        for (uint32_t c = 0; c < channels; c++) p |= (uint32_t)data[i * channels + c] << (8 * c);
+        img.rgba[i] = p;
+    }
+    images.push_back(std::move(img));
+    return (int)images.size() - 1;
+}
+int Scene::add_sampler(const SrSamplerDesc* d) {
+    if (!d || d->mag_filter > 1 || d->min_filter > 1 || d->address_mode_u > 2 || d->address_mode_v > 2) return -1;
+    samplers.push_back(*d);
+    return (int)samplers.size() - 1;
+}
+// rt_utils.slang:121-133
+V4 Scene::sample_texture(uint32_t image_slot, uint32_t sampler_slot, float s, float t, V4 fallback) const {
+    if (image_slot == SR_NULL_TEXTURE) return fallback;
+    return sample_image(images[image_slot], samplers[sampler_slot], s, t);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -399,8 +428,7 @@ bool Scene::any_bvh(V3 o, V3 d, float tmin, float tmax, Counters* c) const {
 
 // ---------------------------------------------------------------------------------------------
 // K4 closest_hit (closest_hit.slang:12-91) and K6 ray_miss (ray_miss.slang:10-13).
-// Textures: only NULL_TEXTURE materials are in scope (sample_texture returns its fallback,
-// rt_utils.slang:127-129); add_mesh callers must pass NULL texture slots.
+// Textures go through Scene::sample_texture (orc_texture.h).
 // ---------------------------------------------------------------------------------------------
 SrRayPayload Scene::shade_hit(const Hit& h) const {
     SrRayPayload pl;
@@ -418,20 +446,47 @@ SrRayPayload Scene::shade_hit(const Hit& h) const {
     auto P3 = [](const float* p) { return v3(p[0], p[1], p[2]); };
     V3 normal = P3(a.normal) * bary.x + P3(b.normal) * bary.y + P3(c.normal) * bary.z;           // :31
     V3 tangent_dir = P3(a.tangent) * bary.x + P3(b.tangent) * bary.y + P3(c.tangent) * bary.z;   // :32
-    (void)tangent_dir;  // only feeds the normal-map branch (:56-72), which needs a normal texture
-    V3 base_color = v3(m.base_color_value[0], m.base_color_value[1], m.base_color_value[2]);    // :42 (fallback)
-    V3 emissive_sample = v3(m.emissive_factor[0], m.emissive_factor[1], m.emissive_factor[2]);  // :45 (fallback)
-    V3 final_emission = emissive_sample * m.emissive_factor[3];                                  // :46
+    float handedness = a.tangent[3] >= 0.0f ? 1.0f : -1.0f;                                      // :34
+    float uv_s = (a.base_color_tex_coord[0] * bary.x + b.base_color_tex_coord[0] * bary.y) + c.base_color_tex_coord[0] * bary.z;  // :36
+    float uv_t = (a.base_color_tex_coord[1] * bary.x + b.base_color_tex_coord[1] * bary.y) + c.base_color_tex_coord[1] * bary.z;
+    float nuv_s = (a.normal_tex_coord[0] * bary.x + b.normal_tex_coord[0] * bary.y) + c.normal_tex_coord[0] * bary.z;             // :37
+    float nuv_t = (a.normal_tex_coord[1] * bary.x + b.normal_tex_coord[1] * bary.y) + c.normal_tex_coord[1] * bary.z;
+    V4 base_color = sample_texture(m.base_color_image, m.base_color_sampler, uv_s, uv_t,
+                                   V4{m.base_color_value[0], m.base_color_value[1], m.base_color_value[2], m.base_color_value[3]});   // :42
+    V4 emissive_sample = sample_texture(m.emissive_image, m.emissive_sampler, uv_s, uv_t,
+                                        V4{m.emissive_factor[0], m.emissive_factor[1], m.emissive_factor[2], 1.0f});                // :45
+    V3 final_emission = v3(emissive_sample.x, emissive_sample.y, emissive_sample.z) * m.emissive_factor[3];                        // :46
     const float* W = inst.w2o;                                                                   // :49-50
     V3 world_normal = normalize(v3((normal.x * W[0] + normal.y * W[3]) + normal.z * W[6],
                                    (normal.x * W[1] + normal.y * W[4]) + normal.z * W[7],
                                    (normal.x * W[2] + normal.y * W[5]) + normal.z * W[8]));
     V3 final_normal = world_normal;                                                              // :51
+    if (length(tangent_dir) > 0.001f && m.normal_image != SR_NULL_TEXTURE) {                     // :56,65 (the TBN has no other use)
+        const float* M = inst.o2w.m;                                                             // (float3x3)ObjectToWorld3x4, :57
+        V3 world_tangent = normalize(v3((M[0] * tangent_dir.x + M[1] * tangent_dir.y) + M[2] * tangent_dir.z,
+                                        (M[4] * tangent_dir.x + M[5] * tangent_dir.y) + M[6] * tangent_dir.z,
+                                        (M[8] * tangent_dir.x + M[9] * tangent_dir.y) + M[10] * tangent_dir.z));   // :58
+        world_tangent = normalize(world_tangent - world_normal * dot(world_tangent, world_normal));                  // :59
+        V3 world_bitangent = cross(world_normal, world_tangent) * handedness;                                        // :60
+        V4 raw = sample_texture(m.normal_image, m.normal_sampler, nuv_s, nuv_t, V4{0.5f, 0.5f, 1.0f, 1.0f});         // :66
+        V3 sn = v3(raw.x * 2.0f - 1.0f, raw.y * 2.0f - 1.0f, raw.z * 2.0f - 1.0f);                                   // :67 (:68 multiplies xy by 1)
+        sn.z = sqrtf(fminf(fmaxf(1.0f - (sn.x * sn.x + sn.y * sn.y), 0.0f), 1.0f));                                  // :69
+        sn = normalize(sn);                                                                                          // :70
+        final_normal = normalize(v3((sn.x * world_tangent.x + sn.y * world_bitangent.x) + sn.z * world_normal.x,
+                                    (sn.x * world_tangent.y + sn.y * world_bitangent.y) + sn.z * world_normal.y,
+                                    (sn.x * world_tangent.z + sn.y * world_bitangent.z) + sn.z * world_normal.z));  // :72 mul(v, TBN)
+    }
     pl.dist = h.t;                                                                               // :74
     pl.emission[0] = final_emission.x; pl.emission[1] = final_emission.y; pl.emission[2] = final_emission.z;
     pl.albedo_packed = pack_unorm_4x8(base_color.x, base_color.y, base_color.z, 1.0f);           // :76
     pl.normal_packed = pack_normal(final_normal);                                                // :77
-    pl.material_info = pack_half_2x16(m.roughness_factor, m.metallic_factor);                    // :79-89
+    float final_roughness = m.roughness_factor, final_metallic = m.metallic_factor;             // :79-80
+    if (m.metallic_roughness_image != SR_NULL_TEXTURE) {                                         // :82-87
+        V4 mr = sample_texture(m.metallic_roughness_image, m.metallic_roughness_sampler, uv_s, uv_t, V4{1.0f, 1.0f, 1.0f, 1.0f});
+        final_roughness = final_roughness * mr.y;
+        final_metallic = final_metallic * mr.z;
+    }
+    pl.material_info = pack_half_2x16(final_roughness, final_metallic);                          // :89
     pl.transmission_ior_packed = pack_half_2x16(m.transmission_factor, m.ior);                   // :90
     return pl;
 }

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "orc_utils.h"
+#include "orc_texture.h"
 
 namespace orc {
 
@@ -52,6 +53,8 @@ struct Scene {
     std::vector<Mesh> meshes;             // slot order
     std::map<uint64_t, uint32_t> slots;   // key -> mesh-info slot
     std::vector<SrEmissiveTriangle> emissive_tris;  // the emissive arena
+    std::vector<Image> images;            // image slot order (Material::*_image)
+    std::vector<SrSamplerDesc> samplers;  // sampler slot order (Material::*_sampler)
     // frame data (resource_manager.rs:216-267 + lib.rs:1058-1081)
     std::vector<Instance> instances;
     std::vector<SrTransform> transforms;
@@ -64,6 +67,9 @@ struct Scene {
     Counters counters;
 
     int add_mesh(uint64_t key, const SrVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const SrMaterial* m);
+    int add_image(const uint8_t* data, uint32_t w, uint32_t h, uint32_t channels);
+    int add_sampler(const SrSamplerDesc* d);
+    V4 sample_texture(uint32_t image_slot, uint32_t sampler_slot, float s, float t, V4 fallback) const;
     int set_instances(const uint64_t* keys, const uint32_t* counts, uint32_t n_keys, const SrTransform* xf);
     uint32_t num_lights() const { return (uint32_t)indirection.size(); }
 

@@ -106,8 +106,10 @@ class SrBvhStats(C.Structure):
 
 
 def material(base_color=(0.8, 0.8, 0.8, 1.0), metallic=0.0, roughness=0.5, emissive_factor=(0.0, 0.0, 0.0),
-             emissive_strength=0.0, transmission=0.0, ior=1.5):
-    """Material::new for a runtime mesh (resources/material.rs:52-92; all textures NULL, lib.rs:937-943)."""
+             emissive_strength=0.0, transmission=0.0, ior=1.5, textures=None):
+    """Material::new (resources/material.rs:52-92). Runtime meshes have all textures NULL (lib.rs:937-943);
+    `textures` = {"base_color"|"metallic_roughness"|"normal"|"occlusion"|"emissive": (image slot, sampler slot)}
+    is what the glTF path's `resolve` closure fills in."""
     m = np.zeros((), dtype=MATERIAL)
     m["base_color_value"] = base_color
     m["metallic_factor"] = metallic
@@ -118,7 +120,18 @@ def material(base_color=(0.8, 0.8, 0.8, 1.0), metallic=0.0, roughness=0.5, emiss
     for k in ("base_color", "metallic_roughness", "normal", "occlusion", "emissive"):
         m[k + "_image"] = NULL_TEXTURE
         m[k + "_sampler"] = NULL_TEXTURE
+    for k, (img, smp) in (textures or {}).items():
+        m[k + "_image"] = img
+        m[k + "_sampler"] = smp
     return m
+
+
+FILTER_NEAREST, FILTER_LINEAR = 0, 1
+ADDRESS_REPEAT, ADDRESS_MIRRORED_REPEAT, ADDRESS_CLAMP_TO_EDGE = 0, 1, 2
+
+
+class SrSamplerDesc(C.Structure):
+    _fields_ = [("min_filter", C.c_uint32), ("mag_filter", C.c_uint32), ("address_mode_u", C.c_uint32), ("address_mode_v", C.c_uint32)]
 
 
 IDENTITY_TRANSFORM = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float32)

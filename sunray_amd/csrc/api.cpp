@@ -63,7 +63,11 @@ struct SrScene {
     std::vector<SrMeshInfo> mesh_infos;
     srh::FrameInstanceData fid;
     std::vector<srh::BuildTri> world_tris;
+    struct DeviceImage { void* d_texels = nullptr; uint32_t w = 0, h = 0; };
+    std::vector<DeviceImage> images;        // image slot order (Material::*_image)
+    std::vector<SrSamplerDesc> samplers;    // sampler slot order (Material::*_sampler)
     DeviceBuffer d_nodes, d_tris, d_shade, d_mesh_const, d_slot_of_gid, d_instances, d_lights, d_misc;
+    DeviceBuffer d_shade_tex, d_mesh_tex, d_textures;
     srd::DevScene dev{};
     SrBvhStats stats{};
     bool built = false;
@@ -172,6 +176,8 @@ int sr_scene_destroy(SrScene* s) {
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
     for (auto& m : s->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
+    for (auto& im : s->images) if (im.d_texels) (void)hipFree(im.d_texels);
+    s->d_shade_tex.release(); s->d_mesh_tex.release(); s->d_textures.release();
     s->d_nodes.release(); s->d_tris.release(); s->d_shade.release(); s->d_mesh_const.release(); s->d_slot_of_gid.release(); s->d_instances.release();
     s->d_lights.release(); s->d_misc.release();
     for (auto& pool : s->events) for (auto& e : pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -194,9 +200,10 @@ int sr_scene_add_mesh(SrScene* s, uint64_t key, const SrVertex* vertices, uint32
             snprintf(buf, sizeof(buf), "load_mesh: index %u out of range for %u vertices", indices[i], n_vertices);
             return fail(SR_ERR_INVALID_ARG, buf);
         }
-    const uint32_t* tex = &material->base_color_image;
+    const uint32_t* tex = &material->base_color_image;   // five (image, sampler) slot pairs (resources/material.rs:33-42)
     for (int i = 0; i < 10; i += 2)
-        if (tex[i] != SR_NULL_TEXTURE) return fail(SR_ERR_UNSUPPORTED, "load_mesh: textured materials are outside the built scope (SURVEY.md §8f #3); pass NULL texture slots");
+        if (tex[i] != SR_NULL_TEXTURE && (tex[i] >= s->images.size() || tex[i + 1] >= s->samplers.size()))
+            return fail(SR_ERR_INVALID_ARG, "load_mesh: material refers to an image or sampler slot that was never added");
     int rc = bind_device(s);
     if (rc != SR_OK) return rc;
     srh::HostMesh m;
@@ -222,6 +229,38 @@ int sr_scene_add_mesh(SrScene* s, uint64_t key, const SrVertex* vertices, uint32
     s->meshes.push_back(std::move(m));
     s->built = false;
     if (out_slot) *out_slot = slot;
+    return SR_OK;
+}
+
+int sr_scene_add_image(SrScene* s, const uint8_t* data, uint32_t width, uint32_t height, uint32_t channels, uint32_t* out_image_slot) {
+    if (!s || !data || width == 0 || height == 0) return fail(SR_ERR_INVALID_ARG, "Image::new_from_data: null argument or empty extent");
+    if (channels < 1 || channels > 4) return fail(SR_ERR_INVALID_ARG, "Image::new_from_data: 1..4 channels of 8 bits are supported");
+    if ((uint64_t)width * height >= (1ull << 30)) return fail(SR_ERR_UNSUPPORTED, "Image::new_from_data: image too large");
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    const size_t n = (size_t)width * height;
+    std::vector<uint32_t> rgba(n);
+    for (size_t i = 0; i < n; i++) {       // utils::realign_data (utils.rs:27-43): missing channels are 0x00
+        uint32_t p = 0;
+        for (uint32_t c = 0; c < channels; c++) p |= (uint32_t)data[i * channels + c] << (8 * c);
+        rgba[i] = p;
+    }
+    SrScene::DeviceImage im;
+    im.w = width; im.h = height;
+    HIP_TRY(hipMalloc(&im.d_texels, n * 4));
+    HIP_TRY(hipMemcpy(im.d_texels, rgba.data(), n * 4, hipMemcpyHostToDevice));
+    s->images.push_back(im);
+    if (out_image_slot) *out_image_slot = (uint32_t)s->images.size() - 1;
+    return SR_OK;
+}
+
+int sr_scene_add_sampler(SrScene* s, const SrSamplerDesc* d, uint32_t* out_sampler_slot) {
+    if (!s || !d) return fail(SR_ERR_INVALID_ARG, "Sampler::new: null argument");
+    if (d->min_filter > SR_FILTER_LINEAR || d->mag_filter > SR_FILTER_LINEAR || d->address_mode_u > SR_ADDRESS_CLAMP_TO_EDGE ||
+        d->address_mode_v > SR_ADDRESS_CLAMP_TO_EDGE)
+        return fail(SR_ERR_INVALID_ARG, "Sampler::new: filter must be NEAREST/LINEAR, address mode REPEAT/MIRRORED_REPEAT/CLAMP_TO_EDGE");
+    s->samplers.push_back(*d);
+    if (out_sampler_slot) *out_sampler_slot = (uint32_t)s->samplers.size() - 1;
     return SR_OK;
 }
 
@@ -260,17 +299,70 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
         mconst[i].material_info = srh::pack_half_2x16(m.roughness_factor, m.metallic_factor);
         mconst[i].transmission_ior_packed = srh::pack_half_2x16(m.transmission_factor, m.ior);
     }
+    // texture side: per-mesh factors + resolved slots, per-slot uv/tangent records, the image table. Occlusion
+    // textures are carried in SrMaterial but no shader on the path samples them.
+    std::vector<srd::DevMeshTex> mtex(mconst.size());
+    memset(mtex.data(), 0, mtex.size() * sizeof(srd::DevMeshTex));
+    bool any_textured = false;
+    auto sampler_code = [&](uint32_t image, uint32_t sampler) -> uint32_t {
+        if (image == SR_NULL_TEXTURE) return 0u;
+        const SrSamplerDesc& d = s->samplers[sampler];
+        return (d.mag_filter & 1u) | (d.address_mode_u << 1) | (d.address_mode_v << 3);
+    };
+    for (size_t i = 0; i < s->meshes.size(); i++) {
+        const SrMaterial& m = s->meshes[i].material;
+        srd::DevMeshTex& t = mtex[i];
+        memcpy(t.base_color, m.base_color_value, 16);
+        memcpy(t.emissive_factor, m.emissive_factor, 12);
+        t.emissive_strength = m.emissive_factor[3];
+        t.roughness = m.roughness_factor; t.metallic = m.metallic_factor;
+        t.img_base = m.base_color_image; t.img_mr = m.metallic_roughness_image; t.img_normal = m.normal_image; t.img_emissive = m.emissive_image;
+        t.samplers = sampler_code(m.base_color_image, m.base_color_sampler) | (sampler_code(m.metallic_roughness_image, m.metallic_roughness_sampler) << 8) |
+                     (sampler_code(m.normal_image, m.normal_sampler) << 16) | (sampler_code(m.emissive_image, m.emissive_sampler) << 24);
+        mconst[i].textured = (t.img_base != SR_NULL_TEXTURE || t.img_mr != SR_NULL_TEXTURE || t.img_normal != SR_NULL_TEXTURE || t.img_emissive != SR_NULL_TEXTURE) ? 1u : 0u;
+        any_textured = any_textured || mconst[i].textured;
+    }
+    std::vector<float> shade_tex;
+    if (any_textured) {
+        shade_tex.assign((size_t)n_tris * 24, 0.0f);
+        for (uint32_t slot = 0; slot < n_tris; slot++) {
+            const srh::BuildTri& t = s->world_tris[bvh.order[slot]];
+            const srh::HostMesh& mesh = s->meshes[s->fid.instances[t.inst].mesh_slot];
+            float* q = &shade_tex[(size_t)slot * 24];
+            const SrVertex* v[3];
+            for (int j = 0; j < 3; j++) v[j] = &mesh.vertices[mesh.indices[3 * t.prim + j]];
+            for (int j = 0; j < 3; j++) {
+                memcpy(q + 2 * j, v[j]->base_color_tex_coord, 8);
+                memcpy(q + 6 + 2 * j, v[j]->normal_tex_coord, 8);
+            }
+            memcpy(q + 12, v[0]->tangent, 12);
+            q[15] = v[0]->tangent[3] >= 0.0f ? 1.0f : -1.0f;   // handedness from the first vertex only (closest_hit.slang:34)
+            memcpy(q + 16, v[1]->tangent, 12);
+            memcpy(q + 19, v[2]->tangent, 12);
+        }
+    }
+    std::vector<srd::DevTexture> textures(s->images.size() ? s->images.size() : 1);
+    memset(textures.data(), 0, textures.size() * sizeof(srd::DevTexture));
+    for (size_t i = 0; i < s->images.size(); i++) { textures[i].texels = (const uint32_t*)s->images[i].d_texels; textures[i].w = s->images[i].w; textures[i].h = s->images[i].h; }
     // device upload (synchronous, like the reference's scene-load BLAS build: blas.rs:178)
     HIP_TRY(hipDeviceSynchronize());
     std::vector<srd::DevInstance> dinst(s->fid.instances.size() ? s->fid.instances.size() : 1);
     memset(dinst.data(), 0, dinst.size() * sizeof(srd::DevInstance));
-    for (size_t i = 0; i < s->fid.instances.size(); i++) memcpy(dinst[i].w2o, s->fid.instances[i].w2o, 36);
+    for (size_t i = 0; i < s->fid.instances.size(); i++) {
+        memcpy(dinst[i].w2o, s->fid.instances[i].w2o, 36);
+        const float* M = s->fid.instances[i].o2w.m;   // (float3x3)ObjectToWorld3x4
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) dinst[i].o2w[3 * r + c] = M[4 * r + c];
+    }
     if ((rc = s->d_nodes.upload(bvh.nodes.data(), bvh.nodes.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_tris.upload(bvh.tris.data(), bvh.tris.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_shade.upload(shade.data(), shade.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_slot_of_gid.upload(slot_of_gid.data(), slot_of_gid.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_mesh_const.upload(mconst.data(), mconst.size() * sizeof(srd::DevMeshConst))) != SR_OK) return rc;
     if ((rc = s->d_instances.upload(dinst.data(), dinst.size() * sizeof(srd::DevInstance))) != SR_OK) return rc;
+    if ((rc = s->d_mesh_tex.upload(mtex.data(), mtex.size() * sizeof(srd::DevMeshTex))) != SR_OK) return rc;
+    if ((rc = s->d_textures.upload(textures.data(), textures.size() * sizeof(srd::DevTexture))) != SR_OK) return rc;
+    if (any_textured) { if ((rc = s->d_shade_tex.upload(shade_tex.data(), shade_tex.size() * 4)) != SR_OK) return rc; }
+    else s->d_shade_tex.release();
     std::vector<float> lights;
     srh::light_table(s->fid, s->emissive_tris, lights);
     if ((rc = s->d_lights.upload(lights.data(), lights.size() * 4)) != SR_OK) return rc;
@@ -278,6 +370,9 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     s->dev.tris = (const float4*)s->d_tris.p;
     s->dev.shade = (const float4*)s->d_shade.p;
     s->dev.mesh_const = (const srd::DevMeshConst*)s->d_mesh_const.p;
+    s->dev.shade_tex = (const float4*)s->d_shade_tex.p;
+    s->dev.mesh_tex = (const srd::DevMeshTex*)s->d_mesh_tex.p;
+    s->dev.textures = (const srd::DevTexture*)s->d_textures.p;
     s->dev.slot_of_gid = (const uint32_t*)s->d_slot_of_gid.p;
     s->dev.instances = (const srd::DevInstance*)s->d_instances.p;
     s->dev.lights = (const srd::DevLight*)s->d_lights.p;
@@ -414,7 +509,7 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
     a.cfg = p->config;
     hipStream_t st = (hipStream_t)stream;
     ScopedTiming tm(s, which == 0 ? kRis : kFinal, st);
-    int e = srk_launch_pass(a, which, s->instrumented, s->stack_entries, st);
+    int e = srk_launch_pass(a, which, s->instrumented, s->dev.shade_tex != nullptr, s->stack_entries, st);
     if (e != 0) return fail(SR_ERR_HIP, std::string(name) + " launch: " + hipGetErrorString((hipError_t)e));
     return SR_OK;
 }

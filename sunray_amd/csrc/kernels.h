@@ -33,7 +33,7 @@ struct PassArgs {
 int srk_launch_trace(const srd::DevScene& sc, const SrRay* rays, uint32_t n, SrHit* hits, uint32_t* occluded,
                      uint32_t* queue_head, int any, int stats, int n_blocks, int stack_entries, hipStream_t stream);
 int srk_launch_shade(const srd::DevScene& sc, const SrHit* hits, uint32_t n, SrRayPayload* out, hipStream_t stream);
-int srk_launch_pass(const srd::PassArgs& args, int which, int stats, int stack_entries, hipStream_t stream);
+int srk_launch_pass(const srd::PassArgs& args, int which, int stats, int textured, int stack_entries, hipStream_t stream);
 
 int srk_launch_post_temporal(const SrPostParams& p, hipStream_t stream);
 int srk_launch_post_denoise(const SrPostParams& p, hipStream_t stream);

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void shade_closest_hit_kernel(DevScene sc, 
     TravHit th;
     th.t = h.t; th.u = h.u; th.v = h.v; th.gid = (h.t < 0.0f || h.tri >= sc.n_tris) ? 0xFFFFFFFFu : h.tri;
     th.slot = (th.gid != 0xFFFFFFFFu) ? sc.slot_of_gid[th.gid] : 0u;
-    const Payload p = shade_hit(sc, th);
+    const Payload p = shade_hit<true>(sc, th);
     SrRayPayload o;
     o.emission[0] = p.emission.x; o.emission[1] = p.emission.y; o.emission[2] = p.emission.z;
     o.dist = p.dist; o.albedo_packed = p.albedo_packed; o.normal_packed = p.normal_packed;
@@ -101,21 +101,21 @@ struct PixelCtx {
     TravStats st;
 };
 
-template <bool STATS>
+template <int V>
 SRD Payload trace_closest_shaded(PixelCtx& cx, f3 o, f3 d, float tmin, float tmax) {
     TravHit h;
-    traverse<false, STATS>(cx.a.sc, o, d, tmin, tmax, h, cx.stack, kBlock, cx.st);
+    traverse<false, (V & 1) != 0>(cx.a.sc, o, d, tmin, tmax, h, cx.stack, kBlock, cx.st);
     cx.n_closest++;
-    return shade_hit(cx.a.sc, h);
+    return shade_hit<(V & 2) != 0>(cx.a.sc, h);
 }
 // The shadow-ray idiom of every visibility query: prd.dist preset to 1.0, the miss shader writes -1;
 // segments <= 0.002 are not traced and count as visible. Returns the resulting prd.dist.
-template <bool STATS>
+template <int V>
 SRD float trace_shadow(PixelCtx& cx, f3 o, f3 d, float dist) {
     if (dist > 0.002f) {
         TravHit h;
         cx.n_any++;
-        return traverse<true, STATS>(cx.a.sc, o, d, 0.001f, dist - 0.001f, h, cx.stack, kBlock, cx.st) ? 1.0f : -1.0f;
+        return traverse<true, (V & 1) != 0>(cx.a.sc, o, d, 0.001f, dist - 0.001f, h, cx.stack, kBlock, cx.st) ? 1.0f : -1.0f;
     }
     return -1.0f;
 }
@@ -193,7 +193,7 @@ SRD bool thread_pixel(const PassArgs& a, uint32_t& px, uint32_t& py) {
     return px < a.width && py < a.y1;
 }
 
-template <bool STATS>
+template <int V>
 __global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kBlock], sized at launch
     PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
         float virtual_distance = 0.0f;
 
         for (uint32_t vb = 0; vb < a.cfg.virtual_bounces; vb++) {
-            prd = trace_closest_shaded<STATS>(cx, rayOrigin, rayDir, 0.001f, 10000.0f);
+            prd = trace_closest_shaded<V>(cx, rayOrigin, rayDir, 0.001f, 10000.0f);
             if (prd.dist < 0.0f) break;
             hitPos = rayOrigin + rayDir * prd.dist;
             hit_normal = unpack_normal(prd.normal_packed);
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
                 vis_dir = vis_dir / vis_dist;
                 if (dot3(hit_normal, vis_dir) <= 0.0f) current_r.W = 0.0f;
                 else {
-                    prd.dist = trace_shadow<STATS>(cx, hitPos + hit_normal * 0.001f, vis_dir, vis_dist);
+                    prd.dist = trace_shadow<V>(cx, hitPos + hit_normal * 0.001f, vis_dir, vis_dist);
                     if (prd.dist >= 0.0f) current_r.W = 0.0f;
                 }
             }
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
             const float gi_NdotL = fmaxf(dot3(hit_normal, gi_dir), 0.0f);
             if (gi_NdotL > 0.0f) {
                 const f3 gi_origin = hitPos + hit_normal * 0.001f;
-                prd = trace_closest_shaded<STATS>(cx, gi_origin, gi_dir, 0.001f, 10000.0f);
+                prd = trace_closest_shaded<V>(cx, gi_origin, gi_dir, 0.001f, 10000.0f);
                 f3 sample_pos = splat(0.0f), sample_normal = splat(0.0f), sample_radiance = splat(0.0f);
                 if (prd.dist > 0.0f) {
                     sample_pos = gi_origin + gi_dir * prd.dist;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
                         const float nee_cos_surf = fmaxf(dot3(sample_normal, to_light), 0.0f);
                         const float nee_cos_light = fmaxf(dot3(nee_normal, -to_light), 0.0f);
                         if (nee_cos_surf > 0.0f && nee_cos_light > 0.0f) {
-                            prd.dist = trace_shadow<STATS>(cx, sample_pos + sample_normal * 0.001f, to_light, nee_dist);
+                            prd.dist = trace_shadow<V>(cx, sample_pos + sample_normal * 0.001f, to_light, nee_dist);
                             if (prd.dist < 0.0f) {
                                 const float nee_pdf_sa = (nee_dist * nee_dist) / fmaxf(nee_cos_light * nee_area * (float)num_lights, 0.0001f);
                                 sample_radiance = sample_radiance + (lt.emission * x2_albedo * nee_cos_surf) / (nee_pdf_sa * 3.14159f);
@@ -429,11 +429,11 @@ __global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
     if (!(a.cfg.flags & SR_TRACE_FLAG_UNCOUNTED)) {
         flush_counter(sc.counters + 0, cx.n_closest);
         flush_counter(sc.counters + 1, cx.n_any);
-        if (STATS) { flush_counter(sc.counters + 2, cx.st.boxes); flush_counter(sc.counters + 3, cx.st.tris); }
+        if (V & 1) { flush_counter(sc.counters + 2, cx.st.boxes); flush_counter(sc.counters + 3, cx.st.tris); }
     }
 }
 
-template <bool STATS>
+template <int V>
 __global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kBlock], sized at launch
     PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
             bool prev_did_nee = false;
 
             for (int bounce = 0; bounce < BOUNCES; bounce++) {
-                prd = trace_closest_shaded<STATS>(cx, rayOrigin, rayDir, 0.001f, 10000.0f);
+                prd = trace_closest_shaded<V>(cx, rayOrigin, rayDir, 0.001f, 10000.0f);
                 if (prd.dist < 0.0f) break;
                 const f3 hit_normal = unpack_normal(prd.normal_packed);
                 const f3 hit_albedo = unpack_unorm_rgb(prd.albedo_packed);
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
                             const float shadow_dist = fmaxf(len3(shadow_dir), 0.0001f);
                             shadow_dir = shadow_dir / shadow_dist;
                             if (dot3(hit_normal, shadow_dir) > 0.0f) {
-                                prd.dist = trace_shadow<STATS>(cx, hitPos, shadow_dir, shadow_dist);
+                                prd.dist = trace_shadow<V>(cx, hitPos, shadow_dir, shadow_dist);
                                 if (prd.dist < 0.0f) radiance = radiance + f_y_winner * throughput * spatial_r.W;
                                 prev_did_nee = true;
                             }
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
                             jacobian = clampf(jacobian, 0.0f, 10.0f);
                             const f3 gi_spatial_dir = w_new / d_new;
                             if (dot3(hit_normal, gi_spatial_dir) <= 0.0f) continue;
-                            prd.dist = trace_shadow<STATS>(cx, hitPos, gi_spatial_dir, d_new);
+                            prd.dist = trace_shadow<V>(cx, hitPos, gi_spatial_dir, d_new);
                             if (prd.dist >= 0.0f) continue;
                             const float p_hat_neighbor = gi_target_pdf(hitPos, hit_normal, hit_albedo, metallic, nsp, ld3(nr.sample_radiance));
                             const float gr = rnd(rng);
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
                             gi_x2_dir = gi_x2_dir / gi_x2_dist;
                             const float gi_NdotL = fmaxf(dot3(hit_normal, gi_x2_dir), 0.0f);
                             if (gi_NdotL > 0.0f) {
-                                prd.dist = trace_shadow<STATS>(cx, hitPos, gi_x2_dir, gi_x2_dist);
+                                prd.dist = trace_shadow<V>(cx, hitPos, gi_x2_dir, gi_x2_dist);
                                 if (prd.dist < 0.0f) {
                                     const f3 gi_f_diffuse = hit_albedo * (1.0f - metallic) / 3.14159f;
                                     radiance = radiance + ld3(combined.sample_radiance) * gi_f_diffuse * gi_NdotL * combined.W * throughput;
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
                         const float cos_theta_light = fmaxf(dot3(light_normal, -shadow_ray_dir), 0.0f);
                         const float cos_theta_surface = fmaxf(dot3(hit_normal, shadow_ray_dir), 0.0f);
                         if (cos_theta_light > 0.0f && cos_theta_surface > 0.0f) {
-                            prd.dist = trace_shadow<STATS>(cx, hitPos, shadow_ray_dir, light_dist);
+                            prd.dist = trace_shadow<V>(cx, hitPos, shadow_ray_dir, light_dist);
                             if (prd.dist < 0.0f) {
                                 const float solid_angle_pdf = (light_dist * light_dist) / fmaxf(cos_theta_light * light_area * (float)num_lights, 1e-4f);
                                 const f3 nee_contrib = (lt.emission * hit_albedo * throughput * cos_theta_surface) / (solid_angle_pdf * 3.14159f);
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
     if (!(a.cfg.flags & SR_TRACE_FLAG_UNCOUNTED)) {
         flush_counter(sc.counters + 0, cx.n_closest);
         flush_counter(sc.counters + 1, cx.n_any);
-        if (STATS) { flush_counter(sc.counters + 2, cx.st.boxes); flush_counter(sc.counters + 3, cx.st.tris); }
+        if (V & 1) { flush_counter(sc.counters + 2, cx.st.boxes); flush_counter(sc.counters + 3, cx.st.tris); }
     }
 }
 
@@ -729,17 +729,28 @@ int srk_launch_shade(const DevScene& sc, const SrHit* hits, uint32_t n, SrRayPay
     return (int)hipGetLastError();
 }
 
-int srk_launch_pass(const PassArgs& args, int which, int stats, int stack_entries, hipStream_t stream) {
+// Kernel variant V: bit 0 = traversal statistics (instrumented build), bit 1 = the scene has textured materials
+// (closest_hit's texture half compiled in). Untextured scenes run the variant without it.
+int srk_launch_pass(const PassArgs& args, int which, int stats, int textured, int stack_entries, hipStream_t stream) {
     const uint32_t n_tiles = args.tiles_x * args.tiles_y;
     if (n_tiles == 0) return 0;
     dim3 grid(args.tiles_per_xcd * 8), block(kBlock);
     const size_t lds = (size_t)stack_entries * kBlock * sizeof(int);
+    const int v = (stats ? 1 : 0) | (textured ? 2 : 0);
     if (which == 0) {
-        if (stats) ris_kernel<true><<<grid, block, lds, stream>>>(args);
-        else ris_kernel<false><<<grid, block, lds, stream>>>(args);
+        switch (v) {
+            case 0: ris_kernel<0><<<grid, block, lds, stream>>>(args); break;
+            case 1: ris_kernel<1><<<grid, block, lds, stream>>>(args); break;
+            case 2: ris_kernel<2><<<grid, block, lds, stream>>>(args); break;
+            default: ris_kernel<3><<<grid, block, lds, stream>>>(args); break;
+        }
     } else {
-        if (stats) final_kernel<true><<<grid, block, lds, stream>>>(args);
-        else final_kernel<false><<<grid, block, lds, stream>>>(args);
+        switch (v) {
+            case 0: final_kernel<0><<<grid, block, lds, stream>>>(args); break;
+            case 1: final_kernel<1><<<grid, block, lds, stream>>>(args); break;
+            case 2: final_kernel<2><<<grid, block, lds, stream>>>(args); break;
+            default: final_kernel<3><<<grid, block, lds, stream>>>(args); break;
+        }
     }
     return (int)hipGetLastError();
 }

@@ -28,15 +28,32 @@ constexpr int kStackMax = 32;         // LDS stack entries per lane the builder 
 constexpr int kMaxBinaryDepth = 32;  // depth bound of the binary tree the 4-wide tree is collapsed from
 constexpr int kSentinel = 0x7fffffff;
 
-struct DevInstance {   // 48 B: (float3x3)WorldToObject3x4, row-major, padded to 3 x float4
+struct DevInstance {   // 96 B: (float3x3)WorldToObject3x4 in w2o[0..8], (float3x3)ObjectToWorld3x4 in o2w[0..8], row-major
     float w2o[12];
+    float o2w[12];         // only the normal-map branch reads it (closest_hit.slang:57-58)
 };
-struct DevMeshConst {  // 32 B: the per-mesh constants of the 32-byte RayPayload (no textures in scope)
+struct DevMeshConst {  // 32 B: the per-mesh constants of the 32-byte RayPayload; complete for untextured meshes
     float emission[3];           // emissive_factor.rgb * strength      (closest_hit.slang:43-46)
     uint32_t albedo_packed;      // pack_unorm_4x8(base_color.rgb, 1)   (:76)
     uint32_t material_info;      // pack_half_2x16(roughness, metallic) (:79-89)
     uint32_t transmission_ior_packed;  // (:90)
-    uint32_t _pad[2];
+    uint32_t textured;           // != 0: any of the four sampled texture slots is set -> DevMeshTex + shade_tex apply
+    uint32_t _pad;
+};
+// Texture side of a material (closest_hit.slang:42-46,65-66,82-87): factors (the sample_texture fallbacks) and the
+// resolved (image, sampler) slots. Sampler codes: bit0 = mag filter LINEAR, bits1-2 = address mode u, bits3-4 = v.
+struct DevMeshTex {    // 64 B
+    float base_color[4];
+    float emissive_factor[3], emissive_strength;
+    float roughness, metallic;
+    uint32_t img_base, img_mr;
+    uint32_t img_normal, img_emissive;
+    uint32_t samplers;           // base | mr << 8 | normal << 16 | emissive << 24
+    uint32_t _pad;
+};
+struct DevTexture {    // 16 B: R8G8B8A8_UNORM, one mip level, R in the low byte (image/mod.rs:96-107)
+    const uint32_t* texels;
+    uint32_t w, h;
 };
 
 // One emissive triangle of the frame's light list (= one emissive_indirection entry), with everything the
@@ -54,7 +71,10 @@ struct DevScene {
     const float4* nodes;
     const float4* tris;
     const float4* shade;
+    const float4* shade_tex;       // 6 x float4 per slot: uv[3], normal uv[3], tangent[3], handedness; NULL without textures
     const DevMeshConst* mesh_const;
+    const DevMeshTex* mesh_tex;    // [n_meshes]
+    const DevTexture* textures;    // [n_images]
     const DevInstance* instances;
     const DevLight* lights;        // [num_lights]
     const uint32_t* slot_of_gid;   // global triangle index -> leaf-order slot (sr_shade_closest_hit only)
@@ -244,6 +264,99 @@ struct Payload {
 // vertex attribute (the normal) plus per-mesh constants: one 48-byte shade record, the instance's
 // WorldToObject and a 32-byte DevMeshConst, instead of the reference's MeshInfo -> indices -> vertices
 // pointer chase (4 dependent fetches).
+// `tex.SampleLevel(smp, uv, 0)` (rt_utils.slang:121-133) on a single-mip RGBA8_UNORM image: the magnification
+// filter at LOD 0. Same exact fp32 definition as the oracle's (oracle/orc_texture.h): no texture
+// unit, no fma.
+SRD float wrap_coord(float s, uint32_t mode) {
+    if (!(fabsf(s) < 3.0e38f)) s = 0.0f;
+    if (mode == 0u) return s - floorf(s);
+    if (mode == 1u) return s - 2.0f * floorf(s * 0.5f);
+    return fminf(fmaxf(s, -1.0f), 2.0f);
+}
+SRD uint32_t wrap_index(int i, int n, uint32_t mode) {
+    if (mode == 0u) { int m = i % n; return (uint32_t)(m < 0 ? m + n : m); }
+    if (mode == 1u) {
+        int m = i % (2 * n);
+        if (m < 0) m += 2 * n;
+        return (uint32_t)(m < n ? m : 2 * n - 1 - m);
+    }
+    return (uint32_t)(i < 0 ? 0 : (i > n - 1 ? n - 1 : i));
+}
+SRD float4 texel_unorm(uint32_t p) {
+    return make_float4((float)(p & 0xFFu) / 255.0f, (float)((p >> 8) & 0xFFu) / 255.0f, (float)((p >> 16) & 0xFFu) / 255.0f,
+                       (float)(p >> 24) / 255.0f);
+}
+SRD float4 sample_texture(const DevScene& sc, uint32_t image_slot, uint32_t sampler_code, float s, float t, float4 fallback) {
+    if (image_slot == 0xFFFFFFFFu) return fallback;
+    const DevTexture tx = sc.textures[image_slot];
+    const uint32_t mode_u = (sampler_code >> 1) & 3u, mode_v = (sampler_code >> 3) & 3u;
+    const int W = (int)tx.w, H = (int)tx.h;
+    float u = wrap_coord(s, mode_u) * (float)W;
+    float v = wrap_coord(t, mode_v) * (float)H;
+    if ((sampler_code & 1u) == 0u) {
+        const uint32_t i = wrap_index((int)floorf(u), W, mode_u), j = wrap_index((int)floorf(v), H, mode_v);
+        return texel_unorm(tx.texels[(size_t)j * tx.w + i]);
+    }
+    u = u - 0.5f; v = v - 0.5f;
+    const float fu = floorf(u), fv = floorf(v);
+    const float a = u - fu, b = v - fv;
+    const uint32_t i0 = wrap_index((int)fu, W, mode_u), i1 = wrap_index((int)fu + 1, W, mode_u);
+    const uint32_t j0 = wrap_index((int)fv, H, mode_v), j1 = wrap_index((int)fv + 1, H, mode_v);
+    const float4 t00 = texel_unorm(tx.texels[(size_t)j0 * tx.w + i0]), t10 = texel_unorm(tx.texels[(size_t)j0 * tx.w + i1]);
+    const float4 t01 = texel_unorm(tx.texels[(size_t)j1 * tx.w + i0]), t11 = texel_unorm(tx.texels[(size_t)j1 * tx.w + i1]);
+    const float na = 1.0f - a, nb = 1.0f - b;
+    return make_float4((t00.x * na + t10.x * a) * nb + (t01.x * na + t11.x * a) * b, (t00.y * na + t10.y * a) * nb + (t01.y * na + t11.y * a) * b,
+                       (t00.z * na + t10.z * a) * nb + (t01.z * na + t11.z * a) * b, (t00.w * na + t10.w * a) * nb + (t01.w * na + t11.w * a) * b);
+}
+
+// Textured half of closest_hit (closest_hit.slang:34-46,56-72,82-87): replaces emission, albedo, normal (if normal-
+// mapped) and material_info. Compiled only into the kernel variants launched for scenes that own textured
+// materials (shade_hit<true>), so untextured scenes keep their register budget.
+SRD void shade_textured(const DevScene& sc, uint32_t slot, uint32_t inst, uint32_t mesh, f3 bary, f3 world_normal, Payload& pl) {
+    const float4* q = sc.shade_tex + (size_t)slot * 6;
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+    const DevMeshTex mt = sc.mesh_tex[mesh];
+    const float uv_s = (q0.x * bary.x + q0.z * bary.y) + q1.x * bary.z;
+    const float uv_t = (q0.y * bary.x + q0.w * bary.y) + q1.y * bary.z;
+    const float4 base_color = sample_texture(sc, mt.img_base, mt.samplers & 0xFFu, uv_s, uv_t,
+                                             make_float4(mt.base_color[0], mt.base_color[1], mt.base_color[2], mt.base_color[3]));
+    const float4 emissive = sample_texture(sc, mt.img_emissive, mt.samplers >> 24, uv_s, uv_t,
+                                           make_float4(mt.emissive_factor[0], mt.emissive_factor[1], mt.emissive_factor[2], 1.0f));
+    pl.emission = mk3(emissive.x, emissive.y, emissive.z) * mt.emissive_strength;
+    pl.albedo_packed = pack_unorm_4x8(base_color.x, base_color.y, base_color.z, 1.0f);
+    if (mt.img_normal != 0xFFFFFFFFu) {
+        const float4 q3 = q[3], q4 = q[4], q5 = q[5];
+        const f3 ta = mk3(q3.x, q3.y, q3.z), tb = mk3(q4.x, q4.y, q4.z), tc = mk3(q4.w, q5.x, q5.y);
+        const f3 tangent_dir = ta * bary.x + tb * bary.y + tc * bary.z;
+        if (len3(tangent_dir) > 0.001f) {
+            const float handedness = q3.w;
+            const float nuv_s = (q1.z * bary.x + q2.x * bary.y) + q2.z * bary.z;
+            const float nuv_t = (q1.w * bary.x + q2.y * bary.y) + q2.w * bary.z;
+            const float* M = sc.instances[inst].o2w;
+            f3 wt = norm3(mk3((M[0] * tangent_dir.x + M[1] * tangent_dir.y) + M[2] * tangent_dir.z,
+                              (M[3] * tangent_dir.x + M[4] * tangent_dir.y) + M[5] * tangent_dir.z,
+                              (M[6] * tangent_dir.x + M[7] * tangent_dir.y) + M[8] * tangent_dir.z));
+            wt = norm3(wt - world_normal * dot3(wt, world_normal));
+            const f3 wb = cross3(world_normal, wt) * handedness;
+            const float4 raw = sample_texture(sc, mt.img_normal, (mt.samplers >> 16) & 0xFFu, nuv_s, nuv_t, make_float4(0.5f, 0.5f, 1.0f, 1.0f));
+            f3 sn = mk3(raw.x * 2.0f - 1.0f, raw.y * 2.0f - 1.0f, raw.z * 2.0f - 1.0f);
+            sn.z = sqrtf(fminf(fmaxf(1.0f - (sn.x * sn.x + sn.y * sn.y), 0.0f), 1.0f));
+            sn = norm3(sn);
+            pl.normal_packed = pack_normal(norm3(mk3((sn.x * wt.x + sn.y * wb.x) + sn.z * world_normal.x,
+                                                     (sn.x * wt.y + sn.y * wb.y) + sn.z * world_normal.y,
+                                                     (sn.x * wt.z + sn.y * wb.z) + sn.z * world_normal.z)));
+        }
+    }
+    float roughness = mt.roughness, metallic = mt.metallic;
+    if (mt.img_mr != 0xFFFFFFFFu) {
+        const float4 mr = sample_texture(sc, mt.img_mr, (mt.samplers >> 8) & 0xFFu, uv_s, uv_t, make_float4(1.0f, 1.0f, 1.0f, 1.0f));
+        roughness = roughness * mr.y;
+        metallic = metallic * mr.z;
+    }
+    pl.material_info = pack_half_2x16(roughness, metallic);
+}
+
+template <bool TEX>
 SRD Payload shade_hit(const DevScene& sc, const TravHit& h) {
     Payload pl;
     pl.emission = splat(0.0f);
@@ -267,6 +380,7 @@ SRD Payload shade_hit(const DevScene& sc, const TravHit& h) {
     pl.normal_packed = pack_normal(world_normal);
     pl.material_info = mc.material_info;
     pl.transmission_ior_packed = mc.transmission_ior_packed;
+    if (TEX) { if (mc.textured) shade_textured(sc, h.slot, inst, mesh, bary, world_normal, pl); }
     return pl;
 }
 

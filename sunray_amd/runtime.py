@@ -152,6 +152,21 @@ class Scene:
         check(lib().sr_scene_add_mesh(self._h, C.c_uint64(key), _p(v), C.c_uint32(len(v)), _p(i), C.c_uint32(len(i)), _p(m), C.byref(slot)))
         return slot.value
 
+    # Image::new_from_data (image/mod.rs:82-111) / Sampler::new (image/sampler.rs:44-67)
+    def add_image(self, pixels):
+        a = np.ascontiguousarray(pixels, dtype=np.uint8)
+        h, w = a.shape[0], a.shape[1]
+        ch = 1 if a.ndim == 2 else a.shape[2]
+        slot = C.c_uint32()
+        check(lib().sr_scene_add_image(self._h, _p(a), C.c_uint32(w), C.c_uint32(h), C.c_uint32(ch), C.byref(slot)))
+        return slot.value
+
+    def add_sampler(self, min_filter, mag_filter, address_mode_u, address_mode_v):
+        d = abi.SrSamplerDesc(min_filter, mag_filter, address_mode_u, address_mode_v)
+        slot = C.c_uint32()
+        check(lib().sr_scene_add_sampler(self._h, C.byref(d), C.byref(slot)))
+        return slot.value
+
     # frame_instance_data (resource_manager.rs:216-267) + TLAS build
     def set_instances(self, instances):
         keys = np.array([k for k, _ in instances], dtype=np.uint64)
@@ -162,6 +177,10 @@ class Scene:
         check(lib().sr_scene_set_instances(self._h, _p(keys), _p(counts), C.c_uint32(len(keys)), _p(np.ascontiguousarray(xf))))
 
     def load(self, desc):
+        for img in desc.images:
+            self.add_image(img)
+        for smp in desc.samplers:
+            self.add_sampler(*smp)
         for m in desc.meshes:
             self.add_mesh(m.key, m.vertices, m.indices, m.material)
         self.set_instances(desc.instances)

@@ -26,6 +26,8 @@ class SceneDesc:
     name: str
     meshes: List[MeshDesc] = field(default_factory=list)
     instances: List[Tuple[int, List[np.ndarray]]] = field(default_factory=list)  # (key, [3x4 row-major])
+    images: List[np.ndarray] = field(default_factory=list)     # (h, w, channels) uint8, slot order
+    samplers: List[Tuple[int, int, int, int]] = field(default_factory=list)  # (min, mag, address u, address v), slot order
     camera_pos: Tuple[float, float, float] = (0.0, 0.0, 1.0)   # Camera::default (camera.rs:10-18)
     camera_target: Tuple[float, float, float] = (0.0, 0.0, 0.0)
     fov_y: float = 45.0
@@ -236,3 +238,139 @@ def white_noise_rgba8(w=128, h=128, seed=7):
         v = (_pcg_hash((ii * w + jj).astype(np.uint32) ^ np.uint32(seed * 2654435761 & 0xFFFFFFFF)) >> np.uint32(24)).astype(np.uint8)
     tex = np.stack([v, v, v, np.full_like(v, 255)], axis=-1)
     return np.ascontiguousarray(tex)
+
+
+# ---- config 4: textured atrium ("Sponza-scale" stand-in) ------------------------------
+def _tex_rgba(h, w, fn):
+    jj, ii = np.meshgrid((np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h)
+    return np.ascontiguousarray(np.clip(np.rint(np.stack(fn(jj, ii), axis=-1) * 255.0), 0, 255).astype(np.uint8))
+
+
+def grid_patch(p0, du, dv, nu, nv, normal, tangent, uv_scale=(1.0, 1.0)):
+    """(nu x nv)-quad tessellated parallelogram p0 + a*du + b*dv with uv = (a, b) * uv_scale on every uv set,
+    vertex normal `normal`, tangent (`tangent`, +1)."""
+    a, b = np.meshgrid(np.linspace(0, 1, nu + 1), np.linspace(0, 1, nv + 1), indexing="ij")
+    pos = np.asarray(p0, dtype=np.float64) + a[..., None] * np.asarray(du, dtype=np.float64) + b[..., None] * np.asarray(dv, dtype=np.float64)
+    v = make_vertices(pos.reshape(-1, 3), np.tile(np.asarray(normal, dtype=np.float32), ((nu + 1) * (nv + 1), 1)))
+    v["tangent"] = tuple(tangent) + (1.0,)
+    uv = np.stack([a * uv_scale[0], b * uv_scale[1]], axis=-1).reshape(-1, 2).astype(np.float32)
+    for k in ("base_color", "metallic_roughness", "normal", "occlusion", "emissive"):
+        v[k + "_tex_coord"] = uv
+    i0, j0 = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    vid = lambda i, j: (i * (nv + 1) + j).ravel()
+    a_, b_, c_, d_ = vid(i0, j0), vid(i0 + 1, j0), vid(i0 + 1, j0 + 1), vid(i0, j0 + 1)
+    return v, np.stack([a_, b_, c_, a_, c_, d_], axis=1).ravel().astype(np.uint32)
+
+
+def cylinder(radius, height, segments, rings, u_repeat=4.0, flute=0.0):
+    """Open cylinder around +y with a seam (duplicated column of vertices so u runs 0..u_repeat), optional fluting."""
+    th, yy = np.meshgrid(np.linspace(0, 2 * np.pi, segments + 1), np.linspace(0, 1, rings + 1), indexing="ij")
+    r = radius * (1.0 + flute * np.cos(th * 12.0)) * (1.0 - 0.12 * yy)   # slight taper
+    pos = np.stack([r * np.cos(th), yy * height, r * np.sin(th)], axis=-1).reshape(-1, 3)
+    nrm = np.stack([np.cos(th), np.full_like(th, 0.12 * radius / height), np.sin(th)], axis=-1).reshape(-1, 3)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    v = make_vertices(pos, nrm.astype(np.float32))
+    tan = np.stack([-np.sin(th), np.zeros_like(th), np.cos(th), -np.ones_like(th)], axis=-1).reshape(-1, 4)   # handedness -1
+    v["tangent"] = tan.astype(np.float32)
+    uv = np.stack([th / (2 * np.pi) * u_repeat, yy * 3.0], axis=-1).reshape(-1, 2).astype(np.float32)
+    for k in ("base_color", "metallic_roughness", "normal", "occlusion", "emissive"):
+        v[k + "_tex_coord"] = uv
+    v["normal_tex_coord"] = uv * np.float32(2.0)          # the normal map uses its own uv set (closest_hit.slang:37)
+    i0, j0 = np.meshgrid(np.arange(segments), np.arange(rings), indexing="ij")
+    vid = lambda i, j: (i * (rings + 1) + j).ravel()
+    a_, b_, c_, d_ = vid(i0, j0), vid(i0, j0 + 1), vid(i0 + 1, j0 + 1), vid(i0 + 1, j0)
+    return v, np.stack([a_, b_, c_, a_, c_, d_], axis=1).ravel().astype(np.uint32)
+
+
+def scale_rotate_y(angle, sx, sy, sz, x, y, z):
+    c, sn = np.float32(np.cos(angle)), np.float32(np.sin(angle))
+    return np.array([sx * c, 0, sz * sn, x, 0, sy, 0, y, -sx * sn, 0, sz * c, z], dtype=np.float32)
+
+
+def atrium(columns_per_side=20, col_segments=96, col_rings=30, floor_div=64, tex=512, n_lamps=32, seed=99):
+    """Colonnade around a tiled floor: ~250k triangles in ~120 instances at the defaults, 512^2 procedural
+    base-colour / metallic-roughness / normal / emissive textures, 2*n_lamps emissive triangles, 5 % mirrors.
+    Every sampler path is used: LINEAR+REPEAT (floor, columns), LINEAR+MIRRORED_REPEAT (walls),
+    NEAREST+CLAMP_TO_EDGE (lamps), and 1/3/4-channel image uploads."""
+    s = SceneDesc("atrium", camera_pos=(0.0, 3.2, 17.0), camera_target=(0.0, 2.4, 0.0), fov_y=55.0)
+    F = lambda x, y, sd, sc=6.0, o=5: fbm(x * sc, y * sc, sd, o)
+    # images -------------------------------------------------------------------------------------
+    def marble(u, v):
+        n = F(u, v, seed) * 0.6 + 0.4 * np.abs(np.sin((u * 4 + F(u, v, seed + 1) * 2.5) * np.pi))
+        check = ((np.floor(u * 4) + np.floor(v * 4)) % 2) * 0.25 + 0.6
+        return (0.2 + 0.7 * n * check, 0.2 + 0.65 * n * check, 0.22 + 0.6 * n, np.ones_like(u))
+    def sandstone(u, v):
+        n = F(u, v, seed + 7, 10.0)
+        return (0.55 + 0.35 * n, 0.42 + 0.3 * n, 0.25 + 0.25 * n)                         # RGB: alpha widened to 0
+    def plaster(u, v):
+        n = F(u, v, seed + 13, 3.0)
+        stripe = 0.85 + 0.15 * (np.floor(v * 8) % 2)
+        return (0.3 + 0.6 * n * stripe, 0.3 + 0.55 * n * stripe, 0.35 + 0.5 * n, np.ones_like(u))
+    def met_rough(u, v):                                                                    # G = roughness, B = metallic
+        n = F(u, v, seed + 21, 8.0)
+        return (np.zeros_like(u), 0.3 + 0.7 * n, (F(u, v, seed + 22, 2.0) > 0.62) * 1.0)   # RGB
+    def bump_normal(u, v):
+        e = 1.0 / tex
+        hgt = lambda a, b: F(a, b, seed + 31, 12.0, 4)
+        dx = (hgt(u + e, v) - hgt(u - e, v)) / (2 * e) * 0.02
+        dy = (hgt(u, v + e) - hgt(u, v - e)) / (2 * e) * 0.02
+        n = np.stack([-dx, -dy, np.ones_like(dx)], axis=-1)
+        n /= np.linalg.norm(n, axis=-1, keepdims=True)
+        return (n[..., 0] * 0.5 + 0.5, n[..., 1] * 0.5 + 0.5, n[..., 2] * 0.5 + 0.5, np.ones_like(u))
+    def lamp_glow(u, v):                                                                    # single channel, coarse: NEAREST shows texels
+        return (np.clip(1.2 - 2.0 * np.hypot(u - 0.5, v - 0.5), 0.0, 1.0),)
+    s.images = [_tex_rgba(tex, tex, marble), _tex_rgba(tex, tex, sandstone), _tex_rgba(tex, tex, plaster), _tex_rgba(tex, tex, met_rough),
+                _tex_rgba(tex, tex, bump_normal), _tex_rgba(max(tex // 32, 4), max(tex // 32, 4), lamp_glow)[..., 0]]
+    IMG_MARBLE, IMG_SAND, IMG_PLASTER, IMG_MR, IMG_NORMAL, IMG_GLOW = range(6)
+    s.samplers = [(abi.FILTER_LINEAR, abi.FILTER_LINEAR, abi.ADDRESS_REPEAT, abi.ADDRESS_REPEAT),
+                  (abi.FILTER_LINEAR, abi.FILTER_LINEAR, abi.ADDRESS_MIRRORED_REPEAT, abi.ADDRESS_MIRRORED_REPEAT),
+                  (abi.FILTER_NEAREST, abi.FILTER_NEAREST, abi.ADDRESS_CLAMP_TO_EDGE, abi.ADDRESS_CLAMP_TO_EDGE),
+                  (abi.FILTER_LINEAR, abi.FILTER_LINEAR, abi.ADDRESS_CLAMP_TO_EDGE, abi.ADDRESS_REPEAT)]
+    SMP_REPEAT, SMP_MIRROR, SMP_NEAREST_CLAMP, SMP_MIXED = range(4)
+    key = [0]
+    def add(v, i, mat, xforms):
+        key[0] += 1
+        s.meshes.append(MeshDesc(key[0], v, i, mat))
+        s.instances.append((key[0], xforms))
+    L, Wd, Hh = 18.0, 9.0, 7.0          # half length (z), half width (x), height
+    # floor: tiled marble with its own mr + normal maps
+    add(*grid_patch((-Wd, 0, L), (2 * Wd, 0, 0), (0, 0, -2 * L), floor_div, floor_div, (0, 1, 0), (1, 0, 0), uv_scale=(6.0, 12.0)),
+        abi.material(base_color=(1, 1, 1, 1), roughness=1.0, metallic=1.0,
+                     textures={"base_color": (IMG_MARBLE, SMP_REPEAT), "metallic_roughness": (IMG_MR, SMP_REPEAT), "normal": (IMG_NORMAL, SMP_REPEAT)}),
+        [abi.IDENTITY_TRANSFORM.copy()])
+    # ceiling + 4 walls: plaster, mirrored repeat; back wall uses the mixed sampler
+    wall = lambda smp: abi.material(base_color=(0.9, 0.9, 0.9, 1), roughness=0.85, textures={"base_color": (IMG_PLASTER, smp), "normal": (IMG_NORMAL, SMP_REPEAT)})
+    wd = max(floor_div // 4, 2)
+    add(*grid_patch((-Wd, Hh, -L), (2 * Wd, 0, 0), (0, 0, 2 * L), wd, wd, (0, -1, 0), (1, 0, 0), (3.0, 6.0)), wall(SMP_MIRROR), [abi.IDENTITY_TRANSFORM.copy()])
+    add(*grid_patch((-Wd, 0, -L), (0, 0, 2 * L), (0, Hh, 0), wd, wd, (1, 0, 0), (0, 0, 1), (5.0, 1.5)), wall(SMP_MIRROR), [abi.IDENTITY_TRANSFORM.copy()])
+    add(*grid_patch((Wd, 0, L), (0, 0, -2 * L), (0, Hh, 0), wd, wd, (-1, 0, 0), (0, 0, -1), (5.0, 1.5)), wall(SMP_MIRROR), [abi.IDENTITY_TRANSFORM.copy()])
+    add(*grid_patch((-Wd, 0, -L), (2 * Wd, 0, 0), (0, Hh, 0), wd, wd, (0, 0, 1), (1, 0, 0), (2.5, 1.5)), wall(SMP_MIXED), [abi.IDENTITY_TRANSFORM.copy()])
+    # columns: one fluted cylinder mesh, 2 rows of instances with per-instance rotation and non-uniform scale
+    cv, ci = cylinder(0.55, 6.2, col_segments, col_rings, flute=0.04)
+    col_mat = abi.material(base_color=(1, 1, 1, 1), roughness=0.9, textures={"base_color": (IMG_SAND, SMP_REPEAT), "normal": (IMG_NORMAL, SMP_REPEAT),
+                                                                              "metallic_roughness": (IMG_MR, SMP_MIRROR)})
+    xs = []
+    for side in (-1, 1):
+        for k in range(columns_per_side):
+            z = -L + 1.5 + (2 * L - 3.0) * k / max(columns_per_side - 1, 1)
+            xs.append(scale_rotate_y(0.37 * k + side, 1.0 + 0.05 * (k % 3), 1.0 + 0.02 * (k % 5), 0.9 + 0.04 * (k % 4), side * 5.5, 0.0, z))
+    add(cv, ci, col_mat, xs)
+    # column bases: untextured boxes-as-patches are skipped; plinth = short wide cylinder, separate mesh, untextured
+    pv, pi = cylinder(0.8, 0.35, max(col_segments // 4, 8), 1)
+    add(pv, pi, abi.material(base_color=(0.5, 0.48, 0.45, 1), roughness=0.6),
+        [translate(side * 5.5, 0.0, -L + 1.5 + (2 * L - 3.0) * k / max(columns_per_side - 1, 1)) for side in (-1, 1) for k in range(columns_per_side)])
+    # mirrors and a glass sphere along the axis (5 % of instances are mirrors)
+    sv, si = uv_sphere(0.9, 32, 16)
+    add(sv, si, abi.material(base_color=(0.95, 0.95, 0.95, 1), metallic=1.0, roughness=0.03),
+        [translate(-2.2, 0.9, 6.0), translate(2.4, 0.9, 1.0), translate(-1.0, 0.9, -5.0), translate(1.6, 0.9, -10.0), scale_rotate_y(0.4, 1.4, 0.7, 1.0, 0.0, 0.63, 9.5)])
+    add(sv, si, abi.material(base_color=(0.9, 0.97, 0.95, 1), roughness=0.05, transmission=1.0, ior=1.45), [translate(0.3, 0.9, 12.0)])
+    # lamps: n_lamps emissive quads under the ceiling, each its own mesh (distinct emission), glow texture NEAREST/clamp
+    for k in range(n_lamps):
+        cx = (-1 if k % 2 else 1) * (2.0 + 1.5 * ((k // 2) % 2))
+        cz = -L + 2.0 + (2 * L - 4.0) * (k // 2) / max(n_lamps // 2 - 1, 1)
+        hue = np.array([1.0, 0.85 + 0.1 * np.sin(k), 0.6 + 0.3 * np.cos(1.7 * k)])
+        lv, li = grid_patch((cx - 0.45, Hh - 0.4, cz - 0.45), (0.9, 0, 0), (0, 0, 0.9), 1, 1, (0, -1, 0), (1, 0, 0))
+        textures = {"emissive": (IMG_GLOW, SMP_NEAREST_CLAMP)} if k % 4 != 3 else None   # every 4th lamp untextured
+        add(lv, li, abi.material(base_color=(0.8, 0.8, 0.8, 1), roughness=0.5, emissive_factor=tuple(hue), emissive_strength=9.0 + (k % 5), textures=textures),
+            [abi.IDENTITY_TRANSFORM.copy()])
+    return s

@@ -19,6 +19,7 @@ CASES = {
     "cornell_box": (scenes.cornell_box, 48, 48, 3, None),
     "cornell_glass_mirror": (scenes.cornell_glass_mirror, 48, 48, 2, None),
     "cornell_box_norestir": (scenes.cornell_box, 48, 48, 2, dict(enable_restir=0, max_bounces=3, shadow_bounces=3)),
+    "atrium_textured": (lambda: scenes.atrium(columns_per_side=3, col_segments=12, col_rings=3, floor_div=6, tex=32, n_lamps=4), 56, 40, 2, None),
 }
 # full frames incl. the post-RT compute chain (temporal accumulation -> 4x a-trous -> tonemap), RGBA8 output
 POST_CASES = {
