@@ -41,7 +41,7 @@ typedef enum SrStatus {
     SR_ERR_HIP = -2,         /* ErrorSource::Vulkan counterpart: a HIP runtime call failed            */
     SR_ERR_OOM = -3,         /* ErrorSource::GpuAllocator                                            */
     SR_ERR_STATE = -4,       /* ErrorSource::RenderGraph: call order violated (e.g. trace before build) */
-    SR_ERR_UNSUPPORTED = -5  /* feature outside the built scope (e.g. textured materials, §8f#3)     */
+    SR_ERR_UNSUPPORTED = -5  /* input outside the built scope (JPEG / 16-bit images, sparse accessors, > 2^28 triangles) */
 } SrStatus;
 
 #define SR_NULL_TEXTURE 0xFFFFFFFFu /* rt_types.slang:192, resources/material.rs:49 */
@@ -297,6 +297,16 @@ int sr_scene_add_mesh(SrScene* scene, uint64_t key, const SrVertex* vertices, ui
                       const uint32_t* indices, uint32_t n_indices, const SrMaterial* material,
                       uint32_t* out_slot);
 
+/* ResourceManager::add_blas (resource_manager.rs:417-447): sr_scene_add_mesh with the local-space emissive
+ * triangles supplied by the caller instead of derived from the material — the glTF path marks a primitive
+ * emissive under a different rule than load_mesh (gltf/mod.rs:272 vs lib.rs:907). */
+int sr_scene_add_blas(SrScene* scene, uint64_t key, const SrVertex* vertices, uint32_t n_vertices,
+                      const uint32_t* indices, uint32_t n_indices, const SrMaterial* material,
+                      const SrEmissiveTriangle* emissive, uint32_t n_emissive, uint32_t* out_slot);
+/* ResourceManager::remove (resource_manager.rs:459-487): frees the mesh-info slot and the emissive slots of
+ * `key` (later loads reuse them LIFO, as the reference's arenas do). Unknown key: no-op. Waits for the device. */
+int sr_scene_remove(SrScene* scene, uint64_t key);
+
 /* Image::new_from_data (image/mod.rs:82-111): `channels` = 1..4 bytes per texel; fewer than 4 are
  * widened to R8G8B8A8_UNORM with the missing channels 0x00 (utils.rs:27-43), no sRGB decode. Host
  * pointer, w*h*channels bytes. Returns the image slot materials refer to (Material::*_image). */
@@ -446,6 +456,44 @@ int sr_renderer_wait_frame(SrRenderer* renderer, uint64_t frame);
 int sr_renderer_render_to_host_memory(SrRenderer* renderer, const float cam_pos[3], const float cam_target[3],
                                       float fov_y_degrees, const uint64_t* keys, const uint32_t* counts, uint32_t n_keys,
                                       const SrTransform* transforms, uint8_t* out_rgba8);
+/* ------------------------------------------------------------------------------------------ */
+/* glTF ingest                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+/* Host-side parse: Gltf::new + create_default_scene (gltf/mod.rs:57-373) and the CPU side of
+ * Scene::load_into_gpu (scene.rs:52-176). `.glb` or `.gltf` (+ external / data: buffers), PNG images (8-bit);
+ * JPEG, 16-bit PNG, sparse accessors, camera/light nodes -> SR_ERR_UNSUPPORTED. No device needed. */
+typedef struct SrGltf SrGltf;
+int sr_gltf_open(const char* path, SrGltf** out);
+int sr_gltf_close(SrGltf* gltf);
+int sr_gltf_counts(const SrGltf* gltf, uint32_t* n_blases, uint32_t* n_instances, uint32_t* n_images,
+                   uint32_t* n_samplers, uint32_t* n_textures);
+/* One unique BLAS (scene.rs:16-24). `material` is UNRESOLVED like the reference's gltf::Material: its *_image
+ * fields hold glTF texture indices (or SR_NULL_TEXTURE), its *_sampler fields SR_NULL_TEXTURE. */
+int sr_gltf_blas(const SrGltf* gltf, uint32_t i, const SrVertex** vertices, uint32_t* n_vertices,
+                 const uint32_t** indices, uint32_t* n_indices, SrMaterial* material,
+                 const SrEmissiveTriangle** emissive, uint32_t* n_emissive);
+/* i-th (blas index, world transform) of LoadedScene::instances (scene.rs:31-33), node-traversal order. */
+int sr_gltf_instance(const SrGltf* gltf, uint32_t i, uint32_t* blas_index, SrTransform* transform);
+int sr_gltf_image(const SrGltf* gltf, uint32_t i, const uint8_t** pixels, uint32_t* width, uint32_t* height,
+                  uint32_t* channels);
+int sr_gltf_sampler(const SrGltf* gltf, uint32_t i, SrSamplerDesc* out);
+/* textures[i] = {sampler: Option<usize> (-1 = none -> the default LINEAR / CLAMP_TO_EDGE sampler,
+ * resource_manager.rs:128-136,393), source image}. */
+int sr_gltf_texture(const SrGltf* gltf, uint32_t i, int32_t* sampler, uint32_t* source);
+
+/* What Renderer::load_gltf / load_scene return (lib.rs:779-846): the asset group and the scene's instances
+ * grouped per BLAS key in BLAS order. Keys are ResourceKey{group, index} packed as group << 32 | index
+ * (lib.rs:54-58); BLASes take indices 0..n-1, images the following ones (resource_manager.rs:400-410). */
+typedef struct SrLoadedScene SrLoadedScene;
+int sr_renderer_load_gltf(SrRenderer* renderer, const char* path, SrLoadedScene** out);
+int sr_renderer_load_scene(SrRenderer* renderer, const SrGltf* gltf, SrLoadedScene** out);
+int sr_loaded_scene_get(const SrLoadedScene* loaded, uint64_t* group, const uint64_t** keys, const uint32_t** counts,
+                        uint32_t* n_keys, const SrTransform** transforms, uint32_t* n_transforms);
+int sr_loaded_scene_destroy(SrLoadedScene* loaded);
+/* Renderer::unload_scene (lib.rs:849-857) / unload_mesh (lib.rs:965-973). */
+int sr_renderer_unload_scene(SrRenderer* renderer, uint64_t group);
+int sr_renderer_unload_mesh(SrRenderer* renderer, uint64_t key);
+
 /* Harness access: inner scene (counters, stats), device pointers of the RGBA8 output and the fp32
  * radiance, and relative_frame_count. Any out pointer may be NULL. */
 int sr_renderer_get(SrRenderer* renderer, SrScene** scene, const uint32_t** output_rgba8_device,

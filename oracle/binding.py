@@ -117,6 +117,20 @@ class OracleScene:
             raise ValueError("oracle add_mesh rejected the mesh (same checks as Renderer::load_mesh, lib.rs:880-899)")
         return slot
 
+    def add_blas(self, key, vertices, indices, material, emissive):
+        v = np.ascontiguousarray(vertices, dtype=abi.VERTEX)
+        i = np.ascontiguousarray(indices, dtype=np.uint32)
+        m = np.ascontiguousarray(material, dtype=abi.MATERIAL)
+        e = np.ascontiguousarray(emissive, dtype=abi.EMISSIVE_TRIANGLE)
+        slot = lib().orc_scene_add_blas(self._h, C.c_uint64(key), _p(v), C.c_uint32(len(v)), _p(i), C.c_uint32(len(i)), _p(m),
+                                        _p(e) if len(e) else None, C.c_uint32(len(e)))
+        if slot < 0:
+            raise ValueError("oracle add_blas rejected the mesh")
+        return slot
+
+    def remove(self, key):
+        lib().orc_scene_remove(self._h, C.c_uint64(key))
+
     def add_image(self, pixels):
         a = np.ascontiguousarray(pixels, dtype=np.uint8)
         ch = 1 if a.ndim == 2 else a.shape[2]

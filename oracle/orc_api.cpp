@@ -19,6 +19,11 @@ void orc_scene_destroy(void* s) { delete (Scene*)s; }
 int orc_scene_add_mesh(void* s, uint64_t key, const SrVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const SrMaterial* m) {
     return ((Scene*)s)->add_mesh(key, v, nv, idx, ni, m);
 }
+int orc_scene_add_blas(void* s, uint64_t key, const SrVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const SrMaterial* m,
+                       const SrEmissiveTriangle* et, uint32_t n_et) {
+    return ((Scene*)s)->add_blas(key, v, nv, idx, ni, m, et, n_et);
+}
+void orc_scene_remove(void* s, uint64_t key) { ((Scene*)s)->remove(key); }
 int orc_scene_add_image(void* s, const uint8_t* data, uint32_t w, uint32_t h, uint32_t channels) {
     return ((Scene*)s)->add_image(data, w, h, channels);
 }

@@ -122,18 +122,10 @@ void inverse3x3(const SrTransform& t, float o[9]) {
 // Renderer::load_mesh (lib.rs:873-954) + ResourceManager::add_blas (resource_manager.rs:417-447)
 // ---------------------------------------------------------------------------------------------
 int Scene::add_mesh(uint64_t key, const SrVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const SrMaterial* m) {
-    if (slots.count(key)) return -1;                              // lib.rs:880-884
     if (nv == 0 || ni == 0 || (ni % 3) != 0) return -1;           // lib.rs:885-891
     for (uint32_t i = 0; i < ni; i++) if (idx[i] >= nv) return -1;  // lib.rs:892-899
-    const uint32_t* tex = &m->base_color_image;                   // five (image, sampler) pairs
-    for (int i = 0; i < 10; i += 2)
-        if (tex[i] != SR_NULL_TEXTURE && (tex[i] >= images.size() || tex[i + 1] >= samplers.size())) return -1;
-    Mesh mesh;
-    mesh.key = key;
-    mesh.vertices.assign(v, v + nv);
-    mesh.indices.assign(idx, idx + ni);
-    mesh.material = *m;
     // lib.rs:901-925: emission = factor * strength; emissive iff any component > 0
+    std::vector<SrEmissiveTriangle> ets;
     float e[3] = {m->emissive_factor[0] * m->emissive_factor[3], m->emissive_factor[1] * m->emissive_factor[3],
                   m->emissive_factor[2] * m->emissive_factor[3]};
     if (e[0] > 0.0f || e[1] > 0.0f || e[2] > 0.0f) {
@@ -142,14 +134,48 @@ int Scene::add_mesh(uint64_t key, const SrVertex* v, uint32_t nv, const uint32_t
             const float* p0 = v[idx[t]].position; const float* p1 = v[idx[t + 1]].position; const float* p2 = v[idx[t + 2]].position;
             for (int k = 0; k < 3; k++) { et.v0[k] = p0[k]; et.v1[k] = p1[k]; et.v2[k] = p2[k]; et.emission[k] = e[k]; }
             et.v0[3] = et.v1[3] = et.v2[3] = 0.0f; et.emission[3] = 0.0f;
-            mesh.emissive_slots.push_back((uint32_t)emissive_tris.size());
-            emissive_tris.push_back(et);
+            ets.push_back(et);
         }
     }
-    uint32_t slot = (uint32_t)meshes.size();
+    return add_blas(key, v, nv, idx, ni, m, ets.data(), (uint32_t)ets.size());
+}
+
+// ResourceManager::add_blas (resource_manager.rs:417-447)
+int Scene::add_blas(uint64_t key, const SrVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const SrMaterial* m,
+                    const SrEmissiveTriangle* et, uint32_t n_et) {
+    if (slots.count(key)) return -1;                              // lib.rs:880-884
+    if (nv == 0 || ni == 0 || (ni % 3) != 0) return -1;
+    for (uint32_t i = 0; i < ni; i++) if (idx[i] >= nv) return -1;
+    const uint32_t* tex = &m->base_color_image;                   // five (image, sampler) pairs
+    for (int i = 0; i < 10; i += 2)
+        if (tex[i] != SR_NULL_TEXTURE && (tex[i] >= images.size() || tex[i + 1] >= samplers.size())) return -1;
+    Mesh mesh;
+    mesh.key = key;
+    mesh.vertices.assign(v, v + nv);
+    mesh.indices.assign(idx, idx + ni);
+    mesh.material = *m;
+    for (uint32_t i = 0; i < n_et; i++) {
+        uint32_t es;
+        if (!free_emissive_slots.empty()) { es = free_emissive_slots.back(); free_emissive_slots.pop_back(); emissive_tris[es] = et[i]; }
+        else { es = (uint32_t)emissive_tris.size(); emissive_tris.push_back(et[i]); }
+        mesh.emissive_slots.push_back(es);
+    }
+    uint32_t slot;
+    if (!free_mesh_slots.empty()) { slot = free_mesh_slots.back(); free_mesh_slots.pop_back(); meshes[slot] = std::move(mesh); }
+    else { slot = (uint32_t)meshes.size(); meshes.push_back(std::move(mesh)); }
     slots[key] = slot;
-    meshes.push_back(std::move(mesh));
     return (int)slot;
+}
+
+// ResourceManager::remove (resource_manager.rs:459-487)
+void Scene::remove(uint64_t key) {
+    auto it = slots.find(key);
+    if (it == slots.end()) return;
+    Mesh& m = meshes[it->second];
+    for (uint32_t es : m.emissive_slots) free_emissive_slots.push_back(es);
+    m = Mesh();
+    free_mesh_slots.push_back(it->second);
+    slots.erase(it);
 }
 
 // Image::new_from_data (image/mod.rs:82-111) with utils::realign_data (utils.rs:27-43): R8/RG8/RGB8

@@ -67,6 +67,10 @@ struct Scene {
     Counters counters;
 
     int add_mesh(uint64_t key, const SrVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const SrMaterial* m);
+    int add_blas(uint64_t key, const SrVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const SrMaterial* m,
+                 const SrEmissiveTriangle* et, uint32_t n_et);
+    void remove(uint64_t key);
+    std::vector<uint32_t> free_mesh_slots, free_emissive_slots;   // LIFO (buffer/arena_core.rs)
     int add_image(const uint8_t* data, uint32_t w, uint32_t h, uint32_t channels);
     int add_sampler(const SrSamplerDesc* d);
     V4 sample_texture(uint32_t image_slot, uint32_t sampler_slot, float s, float t, V4 fallback) const;

@@ -59,7 +59,9 @@ struct SrScene {
     int device = 0;
     std::vector<srh::HostMesh> meshes;
     std::map<uint64_t, uint32_t> slots;
-    std::vector<SrEmissiveTriangle> emissive_tris;
+    std::vector<SrEmissiveTriangle> emissive_tris;       // the emissive arena (resource_manager.rs:433-443)
+    std::vector<SrEmissiveTriangle> emissive_table;      // what a frame sees: the arena, or one zero entry if it is empty
+    std::vector<uint32_t> free_mesh_slots, free_emissive_slots;   // LIFO reuse, like the reference's arenas (buffer/arena_core.rs)
     std::vector<SrMeshInfo> mesh_infos;
     srh::FrameInstanceData fid;
     std::vector<srh::BuildTri> world_tris;
@@ -185,9 +187,12 @@ int sr_scene_destroy(SrScene* s) {
     return SR_OK;
 }
 
-int sr_scene_add_mesh(SrScene* s, uint64_t key, const SrVertex* vertices, uint32_t n_vertices, const uint32_t* indices,
-                      uint32_t n_indices, const SrMaterial* material, uint32_t* out_slot) {
-    if (!s || !vertices || !indices || !material) return fail(SR_ERR_INVALID_ARG, "load_mesh: null argument");
+// ResourceManager::add_blas (resource_manager.rs:417-447): the mesh-info slot becomes the instance custom index, the
+// local emissive triangles go to the emissive arena.
+int sr_scene_add_blas(SrScene* s, uint64_t key, const SrVertex* vertices, uint32_t n_vertices, const uint32_t* indices,
+                      uint32_t n_indices, const SrMaterial* material, const SrEmissiveTriangle* emissive, uint32_t n_emissive,
+                      uint32_t* out_slot) {
+    if (!s || !vertices || !indices || !material || (n_emissive && !emissive)) return fail(SR_ERR_INVALID_ARG, "load_mesh: null argument");
     if (s->slots.count(key)) return fail(SR_ERR_INVALID_ARG, "load_mesh: an asset is already registered under this key");
     if (n_vertices == 0 || n_indices == 0 || (n_indices % 3) != 0) {
         char buf[200];
@@ -202,7 +207,7 @@ int sr_scene_add_mesh(SrScene* s, uint64_t key, const SrVertex* vertices, uint32
         }
     const uint32_t* tex = &material->base_color_image;   // five (image, sampler) slot pairs (resources/material.rs:33-42)
     for (int i = 0; i < 10; i += 2)
-        if (tex[i] != SR_NULL_TEXTURE && (tex[i] >= s->images.size() || tex[i + 1] >= s->samplers.size()))
+        if (tex[i] != SR_NULL_TEXTURE && (tex[i] >= s->images.size() || tex[i + 1] >= s->samplers.size() || !s->images[tex[i]].d_texels))
             return fail(SR_ERR_INVALID_ARG, "load_mesh: material refers to an image or sampler slot that was never added");
     int rc = bind_device(s);
     if (rc != SR_OK) return rc;
@@ -212,23 +217,67 @@ int sr_scene_add_mesh(SrScene* s, uint64_t key, const SrVertex* vertices, uint32
     m.indices.assign(indices, indices + n_indices);
     m.n_vertices = n_vertices; m.n_indices = n_indices;
     m.material = *material;
-    std::vector<SrEmissiveTriangle> et;
-    srh::emissive_triangles_from_mesh(vertices, indices, n_indices, *material, et);
-    for (const auto& t : et) { m.emissive_slots.push_back((uint32_t)s->emissive_tris.size()); s->emissive_tris.push_back(t); }
     HIP_TRY(hipMalloc(&m.d_vertices, sizeof(SrVertex) * (size_t)n_vertices));
     HIP_TRY(hipMemcpy(m.d_vertices, vertices, sizeof(SrVertex) * (size_t)n_vertices, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&m.d_indices, sizeof(uint32_t) * (size_t)n_indices));
     HIP_TRY(hipMemcpy(m.d_indices, indices, sizeof(uint32_t) * (size_t)n_indices, hipMemcpyHostToDevice));
-    const uint32_t slot = (uint32_t)s->meshes.size();
+    for (uint32_t i = 0; i < n_emissive; i++) {
+        uint32_t es;
+        if (!s->free_emissive_slots.empty()) { es = s->free_emissive_slots.back(); s->free_emissive_slots.pop_back(); s->emissive_tris[es] = emissive[i]; }
+        else { es = (uint32_t)s->emissive_tris.size(); s->emissive_tris.push_back(emissive[i]); }
+        m.emissive_slots.push_back(es);
+    }
     SrMeshInfo mi;
     mi.vertices = (uint64_t)(uintptr_t)m.d_vertices;
     mi.indices = (uint64_t)(uintptr_t)m.d_indices;
     mi.material = *material;
-    s->mesh_infos.push_back(mi);
+    uint32_t slot;
+    if (!s->free_mesh_slots.empty()) {
+        slot = s->free_mesh_slots.back(); s->free_mesh_slots.pop_back();
+        s->mesh_infos[slot] = mi;
+        s->meshes[slot] = std::move(m);
+    } else {
+        slot = (uint32_t)s->meshes.size();
+        s->mesh_infos.push_back(mi);
+        s->meshes.push_back(std::move(m));
+    }
     s->slots[key] = slot;
-    s->meshes.push_back(std::move(m));
     s->built = false;
     if (out_slot) *out_slot = slot;
+    return SR_OK;
+}
+
+int sr_scene_add_mesh(SrScene* s, uint64_t key, const SrVertex* vertices, uint32_t n_vertices, const uint32_t* indices,
+                      uint32_t n_indices, const SrMaterial* material, uint32_t* out_slot) {
+    if (!s || !vertices || !indices || !material) return fail(SR_ERR_INVALID_ARG, "load_mesh: null argument");
+    std::vector<SrEmissiveTriangle> et;
+    if (n_indices % 3 == 0) {
+        bool in_range = true;
+        for (uint32_t i = 0; i < n_indices && in_range; i++) in_range = indices[i] < n_vertices;
+        if (in_range) srh::emissive_triangles_from_mesh(vertices, indices, n_indices, *material, et);   // lib.rs:901-925
+    }
+    return sr_scene_add_blas(s, key, vertices, n_vertices, indices, n_indices, material, et.data(), (uint32_t)et.size(), out_slot);
+}
+
+// ResourceManager::remove (resource_manager.rs:459-487) for a BLAS key: frees the mesh-info slot and the emissive
+// slots (reused LIFO by later loads) and the geometry. The reference defers the reclaim by MAX_FRAMES_IN_FLIGHT
+// frames; here the device is idle-waited instead. Instances of the key must no longer be passed to set_instances.
+int sr_scene_remove(SrScene* s, uint64_t key) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "ResourceManager::remove: scene is null");
+    auto it = s->slots.find(key);
+    if (it == s->slots.end()) return SR_OK;     // removing an unknown key is a no-op in the reference
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    const uint32_t slot = it->second;
+    srh::HostMesh& m = s->meshes[slot];
+    if (m.d_vertices) (void)hipFree(m.d_vertices);
+    if (m.d_indices) (void)hipFree(m.d_indices);
+    for (uint32_t es : m.emissive_slots) s->free_emissive_slots.push_back(es);
+    m = srh::HostMesh();
+    s->free_mesh_slots.push_back(slot);
+    s->slots.erase(it);
+    s->built = false;
     return SR_OK;
 }
 
@@ -271,7 +320,8 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     std::string err;
     if (!srh::frame_instance_data(s->meshes, s->slots, keys, counts, n_keys, transforms, s->fid, err)) return fail(SR_ERR_INVALID_ARG, err);
     if (s->fid.n_triangles >= (1u << 28)) return fail(SR_ERR_UNSUPPORTED, "scene exceeds 2^28 triangles (leaf reference encoding)");
-    if (s->emissive_tris.empty()) { SrEmissiveTriangle z; memset(&z, 0, sizeof(z)); s->emissive_tris.push_back(z); }
+    s->emissive_table = s->emissive_tris;
+    if (s->emissive_table.empty()) { SrEmissiveTriangle z; memset(&z, 0, sizeof(z)); s->emissive_table.push_back(z); }
     srh::flatten_instances(s->meshes, s->fid, s->world_tris);
     srh::BvhResult bvh;
     srh::build_bvh(s->world_tris, (uint32_t)srd::kMaxBinaryDepth, bvh);
@@ -293,6 +343,7 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     std::vector<srd::DevMeshConst> mconst(s->meshes.size() ? s->meshes.size() : 1);
     memset(mconst.data(), 0, mconst.size() * sizeof(srd::DevMeshConst));
     for (size_t i = 0; i < s->meshes.size(); i++) {
+        if (s->meshes[i].n_vertices == 0) continue;      // freed slot (sr_scene_remove)
         const SrMaterial& m = s->meshes[i].material;
         for (int k = 0; k < 3; k++) mconst[i].emission[k] = m.emissive_factor[k] * m.emissive_factor[3];
         mconst[i].albedo_packed = srh::pack_unorm_4x8(m.base_color_value[0], m.base_color_value[1], m.base_color_value[2], 1.0f);
@@ -310,6 +361,7 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
         return (d.mag_filter & 1u) | (d.address_mode_u << 1) | (d.address_mode_v << 3);
     };
     for (size_t i = 0; i < s->meshes.size(); i++) {
+        if (s->meshes[i].n_vertices == 0) continue;
         const SrMaterial& m = s->meshes[i].material;
         srd::DevMeshTex& t = mtex[i];
         memcpy(t.base_color, m.base_color_value, 16);
@@ -364,7 +416,7 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     if (any_textured) { if ((rc = s->d_shade_tex.upload(shade_tex.data(), shade_tex.size() * 4)) != SR_OK) return rc; }
     else s->d_shade_tex.release();
     std::vector<float> lights;
-    srh::light_table(s->fid, s->emissive_tris, lights);
+    srh::light_table(s->fid, s->emissive_table, lights);
     if ((rc = s->d_lights.upload(lights.data(), lights.size() * 4)) != SR_OK) return rc;
     s->dev.nodes = (const float4*)s->d_nodes.p;
     s->dev.tris = (const float4*)s->d_tris.p;
@@ -403,8 +455,8 @@ int sr_scene_get_tables(const SrScene* s, const SrTransform** transforms, uint32
     if (n_instances) *n_instances = (uint32_t)s->fid.transforms.size();
     if (indirection) *indirection = s->fid.emissive_entries.data();
     if (num_lights) *num_lights = (uint32_t)s->fid.emissive_entries.size();
-    if (emissive_triangles) *emissive_triangles = s->emissive_tris.data();
-    if (n_emissive) *n_emissive = (uint32_t)s->emissive_tris.size();
+    if (emissive_triangles) *emissive_triangles = s->emissive_table.data();
+    if (n_emissive) *n_emissive = (uint32_t)s->emissive_table.size();
     if (meshes_info) *meshes_info = s->mesh_infos.data();
     if (n_meshes) *n_meshes = (uint32_t)s->mesh_infos.size();
     return SR_OK;

@@ -5,7 +5,9 @@
 // ResourceKey, lib.rs:54-58). One Renderer = one GPU, one caller thread (the reference is !Send).
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -35,6 +37,18 @@ struct SrRenderer {
     std::vector<SrTransform> last_transforms;
     bool instances_valid = false;
     hipEvent_t frame_done = nullptr;
+    // asset groups of load_scene (lib.rs:802-828): group -> BLAS keys; images stay resident (slots are never reused)
+    uint64_t next_group = 0;
+    std::map<uint64_t, std::vector<uint64_t>> scene_groups;
+    std::map<std::array<uint32_t, 4>, uint32_t> sampler_slots;   // dedup like ResourceManager::sampler_slot (resource_manager.rs:491-499)
+    int default_sampler = -1;                                    // LINEAR / CLAMP_TO_EDGE (resource_manager.rs:128-136)
+};
+
+struct SrLoadedScene {
+    uint64_t group = 0;
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> counts;
+    std::vector<SrTransform> transforms;
 };
 
 namespace {
@@ -230,6 +244,127 @@ int sr_renderer_render_to_host_memory(SrRenderer* r, const float cam_pos[3], con
     }
     R_HIP(hipMemcpy(out_rgba8, r->output, (size_t)r->width * r->height * 4, hipMemcpyDeviceToHost));
     return SR_OK;
+}
+
+// ---- scene loading (lib.rs:779-857, resource_manager.rs:372-413) -------------------------------------------
+namespace {
+int sampler_slot(SrRenderer* r, const SrSamplerDesc& d, uint32_t* out) {
+    const std::array<uint32_t, 4> k = {d.min_filter, d.mag_filter, d.address_mode_u, d.address_mode_v};
+    auto it = r->sampler_slots.find(k);
+    if (it != r->sampler_slots.end()) { *out = it->second; return SR_OK; }
+    int rc = sr_scene_add_sampler(r->scene, &d, out);
+    if (rc == SR_OK) r->sampler_slots[k] = *out;
+    return rc;
+}
+}  // namespace
+
+// Renderer::load_scene: uploads the parsed scene's images, samplers and BLASes under fresh keys of a new group.
+int sr_renderer_load_scene(SrRenderer* r, const SrGltf* g, SrLoadedScene** out) {
+    if (!r || !g || !out) return rfail(SR_ERR_INVALID_ARG, "load_scene: null argument");
+    R_HIP(hipSetDevice(r->device));
+    R_HIP(hipDeviceSynchronize());                       // device_wait_idle (lib.rs:800)
+    uint32_t n_blases = 0, n_instances = 0, n_images = 0, n_samplers = 0, n_textures = 0;
+    int rc = sr_gltf_counts(g, &n_blases, &n_instances, &n_images, &n_samplers, &n_textures);
+    if (rc != SR_OK) return rc;
+    const uint64_t group = r->next_group++;
+    std::vector<uint32_t> image_slots(n_images), smp_slots(n_samplers);
+    for (uint32_t i = 0; i < n_images; i++) {
+        const uint8_t* px; uint32_t w, h, ch;
+        if ((rc = sr_gltf_image(g, i, &px, &w, &h, &ch)) != SR_OK || (rc = sr_scene_add_image(r->scene, px, w, h, ch, &image_slots[i])) != SR_OK) return rc;
+    }
+    for (uint32_t i = 0; i < n_samplers; i++) {
+        SrSamplerDesc d;
+        if ((rc = sr_gltf_sampler(g, i, &d)) != SR_OK || (rc = sampler_slot(r, d, &smp_slots[i])) != SR_OK) return rc;
+    }
+    if (r->default_sampler < 0) {
+        const SrSamplerDesc d = {SR_FILTER_LINEAR, SR_FILTER_LINEAR, SR_ADDRESS_CLAMP_TO_EDGE, SR_ADDRESS_CLAMP_TO_EDGE};
+        uint32_t slot;
+        if ((rc = sampler_slot(r, d, &slot)) != SR_OK) return rc;
+        r->default_sampler = (int)slot;
+    }
+    SrLoadedScene* ls = new SrLoadedScene();
+    ls->group = group;
+    std::vector<uint64_t> group_keys;
+    for (uint32_t b = 0; b < n_blases; b++) {
+        const SrVertex* v; const uint32_t* idx; const SrEmissiveTriangle* et; uint32_t nv, ni, ne;
+        SrMaterial m;
+        if ((rc = sr_gltf_blas(g, b, &v, &nv, &idx, &ni, &m, &et, &ne)) != SR_OK) { delete ls; return rc; }
+        uint32_t* slots = &m.base_color_image;             // Material::new's `resolve` (resource_manager.rs:388-398)
+        for (int k = 0; k < 10; k += 2) {
+            if (slots[k] == SR_NULL_TEXTURE) continue;
+            int32_t smp; uint32_t src;
+            if ((rc = sr_gltf_texture(g, slots[k], &smp, &src)) != SR_OK) { delete ls; return rc; }
+            slots[k] = image_slots[src];
+            slots[k + 1] = smp >= 0 ? smp_slots[smp] : (uint32_t)r->default_sampler;
+        }
+        const uint64_t key = (group << 32) | (uint64_t)b;   // ResourceKey{group, index}
+        if ((rc = sr_scene_add_blas(r->scene, key, v, nv, idx, ni, &m, et, ne, nullptr)) != SR_OK) {
+            for (uint64_t k : group_keys) sr_scene_remove(r->scene, k);
+            delete ls;
+            return rc;
+        }
+        group_keys.push_back(key);
+        ls->keys.push_back(key);
+    }
+    // group the per-instance transforms by BLAS key, preserving order (lib.rs:830-834)
+    std::vector<std::vector<SrTransform>> grouped(n_blases);
+    for (uint32_t i = 0; i < n_instances; i++) {
+        uint32_t b; SrTransform t;
+        if ((rc = sr_gltf_instance(g, i, &b, &t)) != SR_OK) { delete ls; return rc; }
+        grouped[b].push_back(t);
+    }
+    for (uint32_t b = 0; b < n_blases; b++) {
+        ls->counts.push_back((uint32_t)grouped[b].size());
+        ls->transforms.insert(ls->transforms.end(), grouped[b].begin(), grouped[b].end());
+    }
+    r->scene_groups[group] = group_keys;
+    r->instances_valid = false;
+    *out = ls;
+    return SR_OK;
+}
+
+// Renderer::load_gltf (lib.rs:779-786)
+int sr_renderer_load_gltf(SrRenderer* r, const char* path, SrLoadedScene** out) {
+    if (!r || !path || !out) return rfail(SR_ERR_INVALID_ARG, "load_gltf: null argument");
+    SrGltf* g = nullptr;
+    int rc = sr_gltf_open(path, &g);
+    if (rc != SR_OK) return rc;
+    rc = sr_renderer_load_scene(r, g, out);
+    sr_gltf_close(g);
+    return rc;
+}
+
+int sr_loaded_scene_get(const SrLoadedScene* ls, uint64_t* group, const uint64_t** keys, const uint32_t** counts, uint32_t* n_keys,
+                        const SrTransform** transforms, uint32_t* n_transforms) {
+    if (!ls) return rfail(SR_ERR_INVALID_ARG, "sr_loaded_scene_get: null argument");
+    if (group) *group = ls->group;
+    if (keys) *keys = ls->keys.data();
+    if (counts) *counts = ls->counts.data();
+    if (n_keys) *n_keys = (uint32_t)ls->keys.size();
+    if (transforms) *transforms = ls->transforms.data();
+    if (n_transforms) *n_transforms = (uint32_t)ls->transforms.size();
+    return SR_OK;
+}
+int sr_loaded_scene_destroy(SrLoadedScene* ls) { delete ls; return SR_OK; }
+
+// Renderer::unload_scene (lib.rs:849-857): frees every BLAS the load created; instances of those keys must no
+// longer be passed to render.
+int sr_renderer_unload_scene(SrRenderer* r, uint64_t group) {
+    if (!r) return rfail(SR_ERR_INVALID_ARG, "unload_scene: renderer is null");
+    auto it = r->scene_groups.find(group);
+    if (it == r->scene_groups.end()) return SR_OK;
+    for (uint64_t k : it->second) { int rc = sr_scene_remove(r->scene, k); if (rc != SR_OK) return rc; }
+    r->scene_groups.erase(it);
+    r->instances_valid = false;
+    return SR_OK;
+}
+
+// Renderer::unload_mesh (lib.rs:965-973). The reference defers the removal past the frames in flight; here the
+// scene waits for the device, so it is immediate.
+int sr_renderer_unload_mesh(SrRenderer* r, uint64_t key) {
+    if (!r) return rfail(SR_ERR_INVALID_ARG, "unload_mesh: renderer is null");
+    r->instances_valid = false;
+    return sr_scene_remove(r->scene, key);
 }
 
 // Access for harnesses: the scene (counters, stats), the device output image and the frame counter.

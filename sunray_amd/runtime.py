@@ -152,6 +152,19 @@ class Scene:
         check(lib().sr_scene_add_mesh(self._h, C.c_uint64(key), _p(v), C.c_uint32(len(v)), _p(i), C.c_uint32(len(i)), _p(m), C.byref(slot)))
         return slot.value
 
+    def add_blas(self, key, vertices, indices, material, emissive):
+        v = np.ascontiguousarray(vertices, dtype=abi.VERTEX)
+        i = np.ascontiguousarray(indices, dtype=np.uint32)
+        m = np.ascontiguousarray(material, dtype=abi.MATERIAL)
+        e = np.ascontiguousarray(emissive, dtype=abi.EMISSIVE_TRIANGLE)
+        slot = C.c_uint32()
+        check(lib().sr_scene_add_blas(self._h, C.c_uint64(key), _p(v), C.c_uint32(len(v)), _p(i), C.c_uint32(len(i)), _p(m),
+                                      _p(e) if len(e) else None, C.c_uint32(len(e)), C.byref(slot)))
+        return slot.value
+
+    def remove(self, key):
+        check(lib().sr_scene_remove(self._h, C.c_uint64(key)))
+
     # Image::new_from_data (image/mod.rs:82-111) / Sampler::new (image/sampler.rs:44-67)
     def add_image(self, pixels):
         a = np.ascontiguousarray(pixels, dtype=np.uint8)
@@ -313,6 +326,52 @@ def default_noise_texture(w=128, h=128, seed=7):
     return out
 
 
+def _np_from(ptr, n, dt):
+    if n == 0:
+        return np.zeros(0, dtype=dt)
+    buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr.value)
+    return np.frombuffer(buf, dtype=dt).copy()
+
+
+def gltf_parse(path):
+    """sr_gltf_open + accessors -> dict(blases=[dict(vertices, indices, material (unresolved), emissive)], instances=[(blas, 3x4)],
+    images=[(h,w,c) uint8], samplers=[(min, mag, u, v)], textures=[(sampler or -1, source)])."""
+    g = C.c_void_p()
+    check(lib().sr_gltf_open(path.encode(), C.byref(g)))
+    try:
+        nb, ni, nim, ns, nt = (C.c_uint32() for _ in range(5))
+        check(lib().sr_gltf_counts(g, C.byref(nb), C.byref(ni), C.byref(nim), C.byref(ns), C.byref(nt)))
+        out = dict(blases=[], instances=[], images=[], samplers=[], textures=[])
+        for i in range(nb.value):
+            vp, ip, ep = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            nv, nx, ne = C.c_uint32(), C.c_uint32(), C.c_uint32()
+            m = np.zeros((), dtype=abi.MATERIAL)
+            check(lib().sr_gltf_blas(g, C.c_uint32(i), C.byref(vp), C.byref(nv), C.byref(ip), C.byref(nx), _p(m), C.byref(ep), C.byref(ne)))
+            out["blases"].append(dict(vertices=_np_from(vp, nv.value, abi.VERTEX), indices=_np_from(ip, nx.value, np.uint32), material=m,
+                                      emissive=_np_from(ep, ne.value, abi.EMISSIVE_TRIANGLE)))
+        for i in range(ni.value):
+            b = C.c_uint32()
+            t = np.zeros(12, dtype=np.float32)
+            check(lib().sr_gltf_instance(g, C.c_uint32(i), C.byref(b), _p(t)))
+            out["instances"].append((b.value, t))
+        for i in range(nim.value):
+            pp = C.c_void_p()
+            w, h, ch = C.c_uint32(), C.c_uint32(), C.c_uint32()
+            check(lib().sr_gltf_image(g, C.c_uint32(i), C.byref(pp), C.byref(w), C.byref(h), C.byref(ch)))
+            out["images"].append(_np_from(pp, w.value * h.value * ch.value, np.uint8).reshape(h.value, w.value, ch.value))
+        for i in range(ns.value):
+            d = abi.SrSamplerDesc()
+            check(lib().sr_gltf_sampler(g, C.c_uint32(i), C.byref(d)))
+            out["samplers"].append((d.min_filter, d.mag_filter, d.address_mode_u, d.address_mode_v))
+        for i in range(nt.value):
+            sm, src = C.c_int32(), C.c_uint32()
+            check(lib().sr_gltf_texture(g, C.c_uint32(i), C.byref(sm), C.byref(src)))
+            out["textures"].append((sm.value, src.value))
+        return out
+    finally:
+        lib().sr_gltf_close(g)
+
+
 class Renderer:
     """The reference's `Renderer<K>` surface for the built path (src/lib.rs:212-446, 586-639, 873-954,
     984-1238, 1908-1934), over sr_renderer_*. `camera` = (position, target, fov_y_degrees) — the
@@ -346,6 +405,30 @@ class Renderer:
 
     def set_config(self, config):
         check(lib().sr_renderer_set_config(self._h, C.byref(config)))
+
+    def load_gltf(self, path):
+        """Renderer::load_gltf (lib.rs:779-786) -> (group, [(key, [3x4 transforms])])."""
+        ls = C.c_void_p()
+        check(lib().sr_renderer_load_gltf(self._h, path.encode(), C.byref(ls)))
+        try:
+            group, nk, nt = C.c_uint64(), C.c_uint32(), C.c_uint32()
+            kp, cp, tp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            check(lib().sr_loaded_scene_get(ls, C.byref(group), C.byref(kp), C.byref(cp), C.byref(nk), C.byref(tp), C.byref(nt)))
+            keys, counts = _np_from(kp, nk.value, np.uint64), _np_from(cp, nk.value, np.uint32)
+            xf = _np_from(tp, nt.value * 12, np.float32).reshape(-1, 12)
+            inst, o = [], 0
+            for k, c in zip(keys, counts):
+                inst.append((int(k), [xf[o + j].copy() for j in range(int(c))]))
+                o += int(c)
+            return group.value, inst
+        finally:
+            lib().sr_loaded_scene_destroy(ls)
+
+    def unload_scene(self, group):
+        check(lib().sr_renderer_unload_scene(self._h, C.c_uint64(group)))
+
+    def unload_mesh(self, key):
+        check(lib().sr_renderer_unload_mesh(self._h, C.c_uint64(key)))
 
     def render(self, camera, instances):
         pos, tgt, fov = camera

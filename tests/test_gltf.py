@@ -1,0 +1,246 @@
+"""glTF ingest: the C++ loader behind sr_gltf_* must equal the numpy restatement
+oracle/gltf_ref.py byte for byte — on files written here (tests/gltf_util.py: GLB / .gltf + .bin / data: URIs,
+strided and normalised accessors, u8/u16/u32 indices, PNG images of every colour type, node hierarchies with TRS
+and matrix transforms, shared and non-indexed primitives) and, where /root/reference exists (this container, not
+the GPU box), on the reference's five example assets, whose headline facts are also checked against values read
+off the files by hand. No GPU needed: parsing is host-only."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gltf_ref
+from sunray_amd import abi, runtime as rt, scenes
+from sunray_amd._lib import SunrayError
+
+import gltf_util
+
+REF_ASSETS = sorted(glob.glob("/root/reference/examples/assets/*.glb"))
+
+
+def assert_same_parse(path):
+    got = rt.gltf_parse(path)
+    ref = gltf_ref.GltfRef(path)
+    assert len(got["blases"]) == len(ref.blases) and len(got["instances"]) == len(ref.instances)
+    for g, r in zip(got["blases"], ref.blases):
+        assert g["vertices"].tobytes() == r["vertices"].tobytes()
+        assert (g["indices"] == r["indices"]).all()
+        assert g["material"].tobytes() == r["material"].tobytes()
+        assert g["emissive"].tobytes() == r["emissive"].tobytes()
+    for (gb, gx), (rb, rx) in zip(got["instances"], ref.instances):
+        assert gb == rb and gx.tobytes() == rx.tobytes()
+    assert got["samplers"] == ref.samplers and got["textures"] == ref.textures
+    assert len(got["images"]) == len(ref.images)
+    for gi, ri in zip(got["images"], ref.images):
+        assert gi.shape == ri.shape and (gi == ri).all()
+    return got, ref
+
+
+@pytest.mark.skipif(not REF_ASSETS, reason="/root/reference is not present on this machine")
+@pytest.mark.parametrize("path", REF_ASSETS, ids=[os.path.basename(p) for p in REF_ASSETS])
+def test_reference_example_assets(path):
+    got, ref = assert_same_parse(path)
+    assert len(got["images"]) == 0 and len(got["textures"]) == 0          # the example rooms are untextured
+    n_tris = sum(len(got["blases"][b]["indices"]) // 3 for b, _ in got["instances"])
+    assert n_tris > 0
+    lights = [b for b in got["blases"] if len(b["emissive"])]
+    assert len(lights) >= 1
+    for b in got["blases"]:
+        m = b["material"]
+        assert m["alpha_mode"] == 0 and m["base_color_image"] == abi.NULL_TEXTURE and m["ior"] == 1.5
+        assert np.isfinite(b["vertices"]["position"]).all() and np.abs(np.linalg.norm(b["vertices"]["normal"], axis=1) - 1).max() < 1e-3
+    if os.path.basename(path) == "Room.glb":
+        # read off the file: 3 nodes, node 0 = mesh 0 with TWO primitives scaled by 8 and lifted to y = 8; the second
+        # material is the light (emissiveStrength 10, factor 1) -> emission (10,10,10)
+        assert len(got["instances"]) == 4 and len(got["blases"]) == 4
+        x0 = got["instances"][0][1].reshape(3, 4)
+        assert np.allclose(x0, [[8, 0, 0, 0], [0, 8, 0, 8], [0, 0, 8, 0]])
+        assert np.allclose(lights[0]["emissive"]["emission"][0], [10, 10, 10, 0])
+        assert np.allclose(got["blases"][0]["material"]["base_color_value"], [0.8, 0.8, 0.8, 1.0], atol=1e-6)
+        assert got["blases"][0]["material"]["roughness_factor"] == 0.5 and got["blases"][0]["material"]["metallic_factor"] == 0.0
+
+
+def _tri_mesh(b, n=5, seed=0, indices_dtype=np.uint16, stride_pad=0, uv_u16=False, tangents=True, indexed=True, uv_sets=1):
+    rng = np.random.default_rng(seed)
+    pos = rng.normal(size=(3 * n, 3)).astype(np.float32)
+    nrm = rng.normal(size=(3 * n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    attrs = {"POSITION": b.accessor(pos, "VEC3", interleave_pad=stride_pad), "NORMAL": b.accessor(nrm, "VEC3")}
+    if tangents:
+        attrs["TANGENT"] = b.accessor(rng.normal(size=(3 * n, 4)).astype(np.float32), "VEC4")
+    for s in range(uv_sets):
+        if uv_u16:
+            attrs["TEXCOORD_%d" % s] = b.accessor(rng.integers(0, 65536, size=(3 * n, 2)).astype(np.uint16), "VEC2", normalized=True)
+        else:
+            attrs["TEXCOORD_%d" % s] = b.accessor(rng.random((3 * n, 2)).astype(np.float32), "VEC2")
+    prim = {"attributes": attrs}
+    if indexed:
+        prim["indices"] = b.accessor(rng.permutation(3 * n).astype(indices_dtype), "SCALAR")
+    return prim
+
+
+def test_loader_feature_matrix(tmp_path):
+    b = gltf_util.GltfBuilder()
+    rng = np.random.default_rng(1)
+    imgs = [b.image(rng.integers(0, 256, size=(9, 7, c) if c > 1 else (9, 7), dtype=np.uint8), embed=(c % 2 == 0)) for c in (1, 2, 3, 4)]
+    b.add("samplers", {"magFilter": 9728, "minFilter": 9987, "wrapS": 33071, "wrapT": 33648})
+    b.add("samplers", {})                                              # all defaults: LINEAR, REPEAT
+    b.add("textures", {"source": imgs[3], "sampler": 0})
+    b.add("textures", {"source": imgs[2]})                             # no sampler -> default sampler at resolve time
+    b.add("textures", {"source": imgs[0], "sampler": 1})
+    b.add("materials", {"pbrMetallicRoughness": {"baseColorFactor": [0.1, 0.2, 0.3, 0.4], "metallicFactor": 0.25, "roughnessFactor": 0.75,
+                                                 "baseColorTexture": {"index": 0}, "metallicRoughnessTexture": {"index": 1, "texCoord": 1}},
+                        "normalTexture": {"index": 2, "texCoord": 1}, "occlusionTexture": {"index": 1}, "emissiveTexture": {"index": 0},
+                        "emissiveFactor": [0.5, 0.25, 1.0],
+                        "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 3.5}, "KHR_materials_transmission": {"transmissionFactor": 0.9},
+                                       "KHR_materials_ior": {"ior": 1.33}}})
+    b.add("materials", {"emissiveFactor": [0.0, 0.2, 0.0]})            # emissive by factor only: strength defaults to 0 -> zero-emission lights
+    b.add("materials", {"pbrMetallicRoughness": {}})                   # all defaults
+    p0 = _tri_mesh(b, 6, 1, np.uint8, stride_pad=4, uv_sets=2); p0["material"] = 0
+    p1 = _tri_mesh(b, 4, 2, np.uint32, uv_u16=True); p1["material"] = 1
+    p2 = _tri_mesh(b, 3, 3, tangents=False, indexed=False)             # no material, no indices, no tangents
+    p_lines = _tri_mesh(b, 2, 4); p_lines["mode"] = 1                  # LINES: skipped (gltf/mod.rs:362-372)
+    p_shared = dict(p0); p_shared["material"] = 2                      # same accessors as p0: shares its BLAS (first material wins)
+    b.add("meshes", {"primitives": [p0, p_lines, p1]})
+    b.add("meshes", {"primitives": [p2]})
+    b.add("meshes", {"primitives": [p_shared, p2]})
+    child = b.add("nodes", {"mesh": 1, "translation": [1, 2, 3], "rotation": [0.1, 0.2, 0.3, 0.9273618495495704], "scale": [2, 0.5, 1.5]})
+    grand = b.add("nodes", {"mesh": 2, "matrix": [1, 0, 0, 0, 0, 0, -1, 0, 0, 1, 0, 0, 4, 5, 6, 1]})
+    b.doc["nodes"][child]["children"] = [grand]
+    root = b.add("nodes", {"mesh": 0, "children": [child], "scale": [3, 3, 3], "rotation": [0, 0.7071067811865476, 0, 0.7071067811865476]})
+    lone = b.add("nodes", {"mesh": 0, "translation": [-9, 0, 0]})
+    unused = b.add("nodes", {"mesh": 1})                               # not in the scene
+    b.add("scenes", {"nodes": [unused]})
+    b.add("scenes", {"nodes": [root, lone]})
+    b.doc["scene"] = 1
+    for kind in ("glb", "gltf_bin", "gltf_data"):
+        path = str(tmp_path / ("m." + ("glb" if kind == "glb" else "gltf")))
+        if kind == "glb":
+            b.write_glb(path)
+        else:
+            b.write_gltf(path, external_bin=(kind == "gltf_bin"))
+        got, ref = assert_same_parse(path)
+    # structure: root(mesh0: p0,p1) -> child(mesh1: p2) -> grand(mesh2: p_shared = p0's BLAS, p2 again); lone(mesh0).
+    # A non-indexed primitive is keyed by (POSITION accessor, position among the mesh's primitives) (gltf/mod.rs:207-212),
+    # so p2 at position 0 of mesh 1 and at position 1 of mesh 2 become two BLASes with identical data.
+    assert [bi for bi, _ in got["instances"]] == [0, 1, 2, 0, 3, 0, 1]
+    assert len(got["blases"]) == 4 and got["blases"][2]["vertices"].tobytes() == got["blases"][3]["vertices"].tobytes()
+    m0 = got["blases"][0]["material"]
+    assert (m0["base_color_image"], m0["metallic_roughness_image"], m0["normal_image"], m0["occlusion_image"], m0["emissive_image"]) == (0, 1, 2, 1, 0)
+    assert m0["base_color_sampler"] == abi.NULL_TEXTURE                 # unresolved, like gltf::Material
+    assert np.allclose(m0["emissive_factor"], [0.5, 0.25, 1.0, 3.5]) and np.isclose(m0["ior"], 1.33) and np.isclose(m0["transmission_factor"], 0.9)
+    assert len(got["blases"][0]["emissive"]) == 6 and np.allclose(got["blases"][0]["emissive"]["emission"][0], [1.75, 0.875, 3.5, 0])
+    assert len(got["blases"][1]["emissive"]) == 4 and (got["blases"][1]["emissive"]["emission"] == 0).all()   # factor != 0, strength 0
+    v0 = got["blases"][0]["vertices"]
+    assert (v0["metallic_roughness_tex_coord"] == v0["normal_tex_coord"]).all() and not (v0["base_color_tex_coord"] == v0["normal_tex_coord"]).all()
+    d = got["blases"][2]
+    assert (d["indices"] == np.arange(3)).all() and len(d["vertices"]) == 9      # non-indexed: 0..len/3 (gltf/mod.rs:330, sic)
+    assert (d["vertices"]["tangent"] == 0).all() and np.allclose(d["material"]["base_color_value"], 1.0) and d["material"]["metallic_factor"] == 1.0
+    assert got["samplers"] == [(abi.FILTER_LINEAR, abi.FILTER_NEAREST, abi.ADDRESS_CLAMP_TO_EDGE, abi.ADDRESS_MIRRORED_REPEAT),
+                               (abi.FILTER_LINEAR, abi.FILTER_LINEAR, abi.ADDRESS_REPEAT, abi.ADDRESS_REPEAT)]
+    assert got["textures"] == [(0, 3), (-1, 2), (1, 0)]
+    assert [im.shape for im in got["images"]] == [(9, 7, 1), (9, 7, 2), (9, 7, 3), (9, 7, 4)]
+    # root transform: scale 3 and a 90 degree turn about y; the child composes parent * local
+    x_root = got["instances"][0][1].reshape(3, 4)
+    assert np.allclose(x_root, [[0, 0, 3, 0], [0, 3, 0, 0], [-3, 0, 0, 0]], atol=1e-6)
+    x_lone = got["instances"][5][1].reshape(3, 4)
+    assert np.allclose(x_lone, [[1, 0, 0, -9], [0, 1, 0, 0], [0, 0, 1, 0]])
+
+
+def test_png_decoder_against_reference_decoder(tmp_path):
+    """Every PNG colour type / filter the writer can produce, plus palette and low bit depths built by hand."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(9)
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xFFFFFFFF)
+
+    def raw_png(w, h, depth, ctype, rows, extra=b""):
+        data = b"".join(b"\x00" + r for r in rows)
+        return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + extra + chunk(b"IDAT", zlib.compress(data)) + chunk(b"IEND", b"")
+    cases = []
+    for c in (1, 2, 3, 4):
+        for ft in (0, 1, 2, 3, 4, None):
+            cases.append(gltf_util.encode_png(rng.integers(0, 256, size=(6, 11, c), dtype=np.uint8), ft))
+    plte = rng.integers(0, 256, size=(16, 3), dtype=np.uint8)
+    idx4 = rng.integers(0, 16, size=(5, 8), dtype=np.uint8)
+    rows4 = [bytes((idx4[y, 0::2] << 4 | idx4[y, 1::2]).astype(np.uint8)) for y in range(5)]
+    cases.append(raw_png(8, 5, 4, 3, rows4, chunk(b"PLTE", plte.tobytes())))
+    cases.append(raw_png(8, 5, 4, 3, rows4, chunk(b"PLTE", plte.tobytes()) + chunk(b"tRNS", bytes([0, 128, 255]))))
+    cases.append(raw_png(8, 5, 4, 0, rows4))                          # 4-bit grey -> scaled by 17
+    bits = rng.integers(0, 2, size=(3, 16), dtype=np.uint8)
+    cases.append(raw_png(16, 3, 1, 0, [bytes(np.packbits(bits[y])) for y in range(3)]))
+    for k, png in enumerate(cases):
+        b = gltf_util.GltfBuilder()
+        b.doc["images"].append({"bufferView": b.view(png), "mimeType": "image/png"})
+        b.add("textures", {"source": 0})
+        prim = _tri_mesh(b, 1, k)
+        b.add("meshes", {"primitives": [prim]})
+        b.add("scenes", {"nodes": [b.add("nodes", {"mesh": 0})]})
+        path = str(tmp_path / ("p%d.glb" % k))
+        b.write_glb(path)
+        got = rt.gltf_parse(path)["images"][0]
+        want = gltf_ref.decode_png(png)
+        assert got.shape == want.shape and (got == want).all(), k
+    assert (rt.gltf_parse(str(tmp_path / "p26.glb"))["images"][0][..., 0] == idx4 * 17).all()
+
+
+def test_loader_errors(tmp_path):
+    def expect(mutate, text, code=-1):
+        b = gltf_util.GltfBuilder()
+        prim = _tri_mesh(b, 2, 0)
+        b.add("meshes", {"primitives": [prim]})
+        b.add("scenes", {"nodes": [b.add("nodes", {"mesh": 0})]})
+        mutate(b, prim)
+        path = str(tmp_path / "e.glb")
+        b.write_glb(path)
+        with pytest.raises(SunrayError) as e:
+            rt.gltf_parse(path)
+        assert text in e.value.description and e.value.code == code, e.value.description
+    expect(lambda b, p: p["attributes"].pop("NORMAL"), "NORMAL")
+    expect(lambda b, p: p["attributes"].pop("TEXCOORD_0"), "TEXCOORD_0")
+    expect(lambda b, p: b.doc.__setitem__("scene", 3), "No scene with index: 3 found")
+    expect(lambda b, p: b.doc["accessors"][0].__setitem__("sparse", {"count": 1}), "sparse", -5)
+    expect(lambda b, p: b.doc["nodes"][0].__setitem__("camera", 0), "camera", -5)
+    expect(lambda b, p: b.doc["accessors"][0].__setitem__("count", 10 ** 6), "exceeds")
+    expect(lambda b, p: b.doc["images"].append({"bufferView": b.view(b"\xFF\xD8\xFF\xE0 not really a jpeg")}), "JPEG", -5)
+
+    def big_index(b, p):
+        b.doc["accessors"][p["indices"]]["componentType"] = 5123
+        b.doc["bufferViews"][b.doc["accessors"][p["indices"]]["bufferView"]]["byteLength"] = 12
+        b.bin[b.doc["bufferViews"][b.doc["accessors"][p["indices"]]["bufferView"]]["byteOffset"]] = 200
+    expect(big_index, "out of range")
+    with pytest.raises(SunrayError) as e:
+        rt.gltf_parse(str(tmp_path / "does_not_exist.glb"))
+    assert "cannot read" in e.value.description
+    open(tmp_path / "junk.gltf", "w").write("{ not json")
+    with pytest.raises(SunrayError):
+        rt.gltf_parse(str(tmp_path / "junk.gltf"))
+
+
+def test_scene_roundtrip_through_gltf(tmp_path, oracle):
+    """A textured procedural scene written as .glb and read back renders exactly like the original description
+    (checked with the oracle; the GPU leg of the same check is tests/test_gpu_parity.py)."""
+    desc = scenes.atrium(columns_per_side=2, col_segments=8, col_rings=2, floor_div=4, tex=16, n_lamps=2)
+    path = str(tmp_path / "atrium.glb")
+    gltf_util.scene_to_gltf(desc, path)
+    got, ref = assert_same_parse(path)
+    meshes, grouped, images, samplers = ref.loaded(group=0)
+    s2 = oracle.OracleScene()
+    for im in images:
+        s2.add_image(im)
+    for smp in samplers:
+        s2.add_sampler(*smp)
+    for key, v, i, m, et in meshes:
+        s2.add_blas(key, v, i, m, et)
+    s2.set_instances(grouped)
+    s1 = oracle.OracleScene().load(desc)
+    W, H = 48, 32
+    noise = scenes.white_noise_rgba8()
+    f1, f2 = oracle.HostFrame(W, H, noise), oracle.HostFrame(W, H, noise)
+    m = oracle.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H)
+    for s, f in ((s1, f1), (s2, f2)):
+        s.trace_ris(f, m, 0); s.trace_final(f, m, 0)
+    assert f1.raw_color.tobytes() == f2.raw_color.tobytes() and f1.raw_color[:, :3].any()

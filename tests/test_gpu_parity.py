@@ -464,6 +464,79 @@ def test_renderer_resize_and_instance_change(rt, oracle):
     r.close()
 
 
+def _oracle_scene_from_gltf(oracle, path, group, first_image_slot=0, sampler_slots=None, osc=None):
+    from oracle import gltf_ref
+    meshes, grouped, images, samplers = gltf_ref.GltfRef(path).loaded(group, first_image_slot, sampler_slots)
+    osc = osc or oracle.OracleScene()
+    for im in images:
+        osc.add_image(im)
+    for smp in samplers:
+        osc.add_sampler(*smp)
+    for key, v, i, m, et in meshes:
+        osc.add_blas(key, v, i, m, et)
+    return osc, grouped, [k for k, *_ in meshes], len(images)
+
+
+def _oracle_frames(oracle, osc, cam, W, H, n, noise, of=None, prev=None, first_frame=0):
+    of = of or oracle.HostFrame(W, H, noise)
+    for f in range(first_frame, first_frame + n):
+        om = oracle.camera_matrices(cam[0], cam[1], cam[2], W, H, prev)
+        prev = list(om.view_proj)
+        osc.trace_ris(of, om, f); osc.trace_final(of, om, f); oracle.post_chain(of, f)
+    return of, prev
+
+
+def test_renderer_load_gltf_unload_reload(rt, oracle, tmp_path):
+    """Renderer::load_gltf -> render_to_host_memory equals the oracle fed by the numpy glTF restatement; after
+    unload_scene + a second load (mesh-info and emissive slots reused LIFO, new image slots, keys of group 1) the
+    renderer still equals the oracle that replays the same add/remove sequence."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import gltf_util
+    desc = small_atrium()
+    path = str(tmp_path / "atrium.glb")
+    gltf_util.scene_to_gltf(desc, path)
+    W, H = 72, 48
+    cam = (desc.camera_pos, desc.camera_target, desc.fov_y)
+    noise = rt.default_noise_texture()
+    r = rt.Renderer((W, H))
+    group, inst = r.load_gltf(path)
+    sampler_slots = {}
+    osc, grouped, keys, n_img = _oracle_scene_from_gltf(oracle, path, 0, 0, sampler_slots)
+    assert group == 0 and [k for k, _ in inst] == keys and keys[1] == 1
+    for (k1, x1), (k2, x2) in zip(inst, grouped):
+        assert len(x1) == len(x2) and all(a.tobytes() == b.tobytes() for a, b in zip(x1, x2))
+    img = r.render_to_host_memory(cam, inst)
+    osc.set_instances(grouped)
+    of, prev = _oracle_frames(oracle, osc, cam, W, H, 16, noise)
+    assert_bits_equal(of.output, img.view(np.uint32).reshape(-1), "glTF scene, 16 frames")
+    assert len(np.unique(img.reshape(-1, 4), axis=0)) > 500
+    # unload, reload: group 1
+    r.unload_scene(group)
+    with pytest.raises(rt.SunrayError):
+        r.render(cam, inst)                                   # the old keys are gone: "never loaded"
+    for k in keys:
+        osc.remove(k)
+    group2, inst2 = r.load_gltf(path)
+    osc, grouped2, keys2, _ = _oracle_scene_from_gltf(oracle, path, 1, n_img, sampler_slots, osc)
+    assert group2 == 1 and [k for k, _ in inst2] == keys2 and keys2[0] == 1 << 32
+    osc.set_instances(grouped2)
+    for _ in range(2):
+        fr = r.render(cam, inst2)
+    r.wait_frame(fr)
+    of, prev = _oracle_frames(oracle, osc, cam, W, H, 2, noise, of, prev, first_frame=16)
+    import ctypes as C
+    from sunray_amd._lib import lib
+    outp = C.c_void_p()
+    assert lib().sr_renderer_get(r._h, None, C.byref(outp), None, None) == 0
+    got = np.zeros(W * H, dtype=np.uint32)
+    assert C.CDLL("libamdhip64.so").hipMemcpy(got.ctypes.data_as(C.c_void_p), outp, C.c_size_t(got.nbytes), C.c_int(2)) == 0
+    assert_bits_equal(of.output, got, "after unload + reload")
+    # unload_mesh of one key; rendering the rest still works
+    r.unload_mesh(keys2[-1])
+    r.wait_frame(r.render(cam, inst2[:-1]))
+    r.close()
+
+
 # ---- BASELINE.json full sizes ---------------------------------------------------------------------
 def test_full_size_1m_triangles_1080p(rt, oracle, blue_noise):
     """The bench workload itself (1920x1080, 999 714 triangles, reference constants): the oracle is fast
