@@ -297,6 +297,38 @@ int sr_scene_add_mesh(SrScene* scene, uint64_t key, const SrVertex* vertices, ui
                       const uint32_t* indices, uint32_t n_indices, const SrMaterial* material,
                       uint32_t* out_slot);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Acceleration-structure maintenance                                            */
+/* ------------------------------------------------------------------------------------------ */
+/* BuildType / OpType / AsState (acceleration_structure/mod.rs:22-148): the rebuild-vs-update heuristic shared by
+ * the reference's BLAS and TLAS — update in place at most 8 times, then a fast rebuild; after 16 quiet frames one
+ * quality rebuild and back to Optimal. Pure logic, exposed for the host that drives the scene. */
+#define SR_BUILD_RAPIDLY_CHANGING 0u
+#define SR_BUILD_SOMETIMES_CHANGES 1u
+#define SR_BUILD_STATIC 2u
+#define SR_OP_NONE 0u
+#define SR_OP_SLOW_BUILD 1u
+#define SR_OP_FAST_BUILD 2u
+#define SR_OP_UPDATE 3u
+typedef struct SrAsState {
+    uint32_t changing; /* 0 = AsState::Optimal, 1 = AsState::Changing(Dynamic) */
+    uint32_t frames_without_changes;
+    uint32_t number_of_updates_since_last_rebuild;
+    uint32_t _pad;
+} SrAsState;
+void sr_as_state_initial(uint32_t build_type, SrAsState* out);
+uint32_t sr_as_state_next_op(const SrAsState* state, int inputs_changed);
+void sr_as_state_mark_built(SrAsState* state, uint32_t completed_op);
+/* The scene's own state (it is built as SometimesChanges, like the reference's TLAS, resource_manager.rs:119-126)
+ * and the operation sr_scene_set_instances / sr_scene_end_frame last performed (SR_OP_*). */
+int sr_scene_as_state(const SrScene* scene, SrAsState* state, uint32_t* last_op);
+/* A frame whose instance list did not change (Tlas::mark_built(None) + the settle rebuild, tlas.rs:155-191 with
+ * inputs_changed = false): advances the quiet-frame counter and, when AsState asks for it, performs the quality
+ * rebuild. The Renderer facade calls it for every frame that skips sr_scene_set_instances. */
+int sr_scene_end_frame(SrScene* scene);
+/* Debug read-back of the device tree: n_nodes x 16 dwords, n_triangles x 12 floats (either may be NULL). */
+int sr_scene_read_bvh(const SrScene* scene, uint32_t* nodes_out, float* tris_out);
+
 /* ResourceManager::add_blas (resource_manager.rs:417-447): sr_scene_add_mesh with the local-space emissive
  * triangles supplied by the caller instead of derived from the material — the glTF path marks a primitive
  * emissive under a different rule than load_mesh (gltf/mod.rs:272 vs lib.rs:907). */

@@ -135,3 +135,12 @@ class SrSamplerDesc(C.Structure):
 
 
 IDENTITY_TRANSFORM = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float32)
+
+
+class SrAsState(C.Structure):
+    _fields_ = [("changing", C.c_uint32), ("frames_without_changes", C.c_uint32), ("number_of_updates_since_last_rebuild", C.c_uint32),
+                ("_pad", C.c_uint32)]
+
+
+BUILD_RAPIDLY_CHANGING, BUILD_SOMETIMES_CHANGES, BUILD_STATIC = 0, 1, 2
+OP_NONE, OP_SLOW_BUILD, OP_FAST_BUILD, OP_UPDATE = 0, 1, 2, 3

@@ -9,9 +9,11 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "host.h"
+#include "bvh_gpu.h"
 #include "kernels.h"
 
 namespace {
@@ -70,9 +72,17 @@ struct SrScene {
     std::vector<SrSamplerDesc> samplers;    // sampler slot order (Material::*_sampler)
     DeviceBuffer d_nodes, d_tris, d_shade, d_mesh_const, d_slot_of_gid, d_instances, d_lights, d_misc;
     DeviceBuffer d_shade_tex, d_mesh_tex, d_textures;
+    // acceleration-structure maintenance (update in place): per-level node lists, exact node boxes, flatten inputs
+    DeviceBuffer d_level_nodes, d_node_box, d_mesh_infos, d_flat_instances;
+    std::vector<uint32_t> level_offsets;
+    std::vector<uint32_t> shape;            // mesh slot of every instance of the built tree: an UPDATE needs the same layout
+    SrAsState as_state{0, 0, 0, 0};         // SometimesChanges -> Optimal (resource_manager.rs:119-126, mod.rs:86-91)
+    uint32_t last_op = SR_OP_NONE;
+    std::vector<uint64_t> last_keys; std::vector<uint32_t> last_counts; std::vector<SrTransform> last_transforms;
     srd::DevScene dev{};
     SrBvhStats stats{};
     bool built = false;
+    bool built_once = false;
     int instrumented = 0;
     int timing = 0;
     int n_cus = 256;
@@ -180,6 +190,7 @@ int sr_scene_destroy(SrScene* s) {
     for (auto& m : s->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (auto& im : s->images) if (im.d_texels) (void)hipFree(im.d_texels);
     s->d_shade_tex.release(); s->d_mesh_tex.release(); s->d_textures.release();
+    s->d_level_nodes.release(); s->d_node_box.release(); s->d_mesh_infos.release(); s->d_flat_instances.release();
     s->d_nodes.release(); s->d_tris.release(); s->d_shade.release(); s->d_mesh_const.release(); s->d_slot_of_gid.release(); s->d_instances.release();
     s->d_lights.release(); s->d_misc.release();
     for (auto& pool : s->events) for (auto& e : pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -313,15 +324,130 @@ int sr_scene_add_sampler(SrScene* s, const SrSamplerDesc* d, uint32_t* out_sampl
     return SR_OK;
 }
 
+namespace {
+
+// Per-instance device tables (closest_hit's WorldToObject / ObjectToWorld, the flatten inputs) and the light table:
+// everything that follows the instance transforms without touching the tree.
+int upload_instance_tables(SrScene* s) {
+    int rc;
+    std::vector<srd::DevInstance> dinst(s->fid.instances.size() ? s->fid.instances.size() : 1);
+    memset(dinst.data(), 0, dinst.size() * sizeof(srd::DevInstance));
+    std::vector<srd::FlatInstance> flat(dinst.size());
+    memset(flat.data(), 0, flat.size() * sizeof(srd::FlatInstance));
+    for (size_t i = 0; i < s->fid.instances.size(); i++) {
+        memcpy(dinst[i].w2o, s->fid.instances[i].w2o, 36);
+        const float* M = s->fid.instances[i].o2w.m;   // (float3x3)ObjectToWorld3x4
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) dinst[i].o2w[3 * r + c] = M[4 * r + c];
+        memcpy(flat[i].o2w, M, 48);
+        flat[i].tri_offset = s->fid.instances[i].tri_offset;
+        flat[i].mesh_slot = s->fid.instances[i].mesh_slot;
+    }
+    if ((rc = s->d_instances.upload(dinst.data(), dinst.size() * sizeof(srd::DevInstance))) != SR_OK) return rc;
+    if ((rc = s->d_flat_instances.upload(flat.data(), flat.size() * sizeof(srd::FlatInstance))) != SR_OK) return rc;
+    std::vector<float> lights;
+    srh::light_table(s->fid, s->emissive_table, lights);
+    if ((rc = s->d_lights.upload(lights.data(), lights.size() * 4)) != SR_OK) return rc;
+    s->dev.instances = (const srd::DevInstance*)s->d_instances.p;
+    s->dev.lights = (const srd::DevLight*)s->d_lights.p;
+    s->dev.num_lights = (uint32_t)s->fid.emissive_entries.size();
+    s->dev.n_instances = (uint32_t)s->fid.instances.size();
+    return SR_OK;
+}
+
+// OpType::Update: same instance layout, new transforms. The triangles are re-flattened on the device into their
+// existing leaf slots and the quantised nodes are refitted bottom-up; topology, shade records and mesh tables stay.
+int update_in_place(SrScene* s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipDeviceSynchronize());
+    int rc = upload_instance_tables(s);
+    if (rc != SR_OK) return rc;
+    int e = srk_launch_flatten_slots((float4*)s->d_tris.p, (const float4*)s->d_shade.p, (const SrMeshInfo*)s->d_mesh_infos.p,
+                                     (const srd::FlatInstance*)s->d_flat_instances.p, s->fid.n_triangles, nullptr);
+    if (e != 0) return fail(SR_ERR_HIP, std::string("flatten launch failed: ") + hipGetErrorString((hipError_t)e));
+    e = srk_launch_refit((uint32_t*)s->d_nodes.p, (const float4*)s->d_tris.p, (float*)s->d_node_box.p, (const uint32_t*)s->d_level_nodes.p,
+                         s->level_offsets.data(), (uint32_t)s->level_offsets.size() - 1, nullptr);
+    if (e != 0) return fail(SR_ERR_HIP, std::string("refit launch failed: ") + hipGetErrorString((hipError_t)e));
+    HIP_TRY(hipDeviceSynchronize());
+    s->stats.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SR_OK;
+}
+
+int full_build(SrScene* s);
+
+}  // namespace
+
 int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* counts, uint32_t n_keys, const SrTransform* transforms) {
     if (!s || (n_keys && (!keys || !counts))) return fail(SR_ERR_INVALID_ARG, "frame_instance_data: null argument");
     int rc = bind_device(s);
     if (rc != SR_OK) return rc;
     std::string err;
-    if (!srh::frame_instance_data(s->meshes, s->slots, keys, counts, n_keys, transforms, s->fid, err)) return fail(SR_ERR_INVALID_ARG, err);
-    if (s->fid.n_triangles >= (1u << 28)) return fail(SR_ERR_UNSUPPORTED, "scene exceeds 2^28 triangles (leaf reference encoding)");
+    srh::FrameInstanceData fid;
+    if (!srh::frame_instance_data(s->meshes, s->slots, keys, counts, n_keys, transforms, fid, err)) return fail(SR_ERR_INVALID_ARG, err);
+    if (fid.n_triangles >= (1u << 28)) return fail(SR_ERR_UNSUPPORTED, "scene exceeds 2^28 triangles (leaf reference encoding)");
+    s->fid = std::move(fid);
     s->emissive_table = s->emissive_tris;
     if (s->emissive_table.empty()) { SrEmissiveTriangle z; memset(&z, 0, sizeof(z)); s->emissive_table.push_back(z); }
+    uint32_t n_xf = 0;
+    for (uint32_t k = 0; k < n_keys; k++) n_xf += counts[k];
+    s->last_keys.assign(keys, keys + n_keys); s->last_counts.assign(counts, counts + n_keys);
+    s->last_transforms.assign(transforms, transforms + n_xf);
+    // Tlas::queue_build (tlas.rs:155-191): the instance data is new, so the heuristic is asked with inputs_changed =
+    // true; an UPDATE needs the same instance layout (here: the same mesh per instance and unchanged meshes),
+    // anything else is a rebuild. The very first build is the quality build (Tlas::new).
+    bool can_update = s->built && s->shape.size() == s->fid.instances.size() && s->fid.n_triangles > 0;
+    for (size_t i = 0; can_update && i < s->shape.size(); i++) can_update = s->shape[i] == s->fid.instances[i].mesh_slot;
+    uint32_t op;
+    if (!s->built_once) op = SR_OP_SLOW_BUILD;
+    else {
+        op = srh::as_state_next_op(s->as_state, true);
+        if (op == SR_OP_UPDATE && !can_update) op = SR_OP_FAST_BUILD;
+    }
+    rc = op == SR_OP_UPDATE ? update_in_place(s) : full_build(s);
+    if (rc != SR_OK) { s->built = false; return rc; }
+    if (s->built_once) srh::as_state_mark_built(s->as_state, op);
+    s->built_once = true;
+    s->last_op = op;
+    return SR_OK;
+}
+
+int sr_scene_end_frame(SrScene* s) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_end_frame: scene is null");
+    if (!s->built) { s->last_op = SR_OP_NONE; return SR_OK; }
+    const uint32_t op = srh::as_state_next_op(s->as_state, false);
+    if (op == SR_OP_SLOW_BUILD) {
+        int rc = bind_device(s);
+        if (rc != SR_OK) return rc;
+        if ((rc = full_build(s)) != SR_OK) { s->built = false; return rc; }
+    }
+    srh::as_state_mark_built(s->as_state, op);
+    s->last_op = op;
+    return SR_OK;
+}
+
+int sr_scene_as_state(const SrScene* s, SrAsState* state, uint32_t* last_op) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_as_state: scene is null");
+    if (state) *state = s->as_state;
+    if (last_op) *last_op = s->last_op;
+    return SR_OK;
+}
+
+void sr_as_state_initial(uint32_t build_type, SrAsState* out) { if (out) srh::as_state_initial(build_type, out); }
+uint32_t sr_as_state_next_op(const SrAsState* state, int inputs_changed) { return state ? srh::as_state_next_op(*state, inputs_changed != 0) : SR_OP_NONE; }
+void sr_as_state_mark_built(SrAsState* state, uint32_t completed_op) { if (state) srh::as_state_mark_built(*state, completed_op); }
+
+int sr_scene_read_bvh(const SrScene* s, uint32_t* nodes_out, float* tris_out) {
+    if (!s || !s->built) return fail(SR_ERR_STATE, "sr_scene_read_bvh: scene not built");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (nodes_out) HIP_TRY(hipMemcpy(nodes_out, s->d_nodes.p, (size_t)s->stats.n_nodes * 64, hipMemcpyDeviceToHost));
+    if (tris_out && s->fid.n_triangles) HIP_TRY(hipMemcpy(tris_out, s->d_tris.p, (size_t)s->fid.n_triangles * 48, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+namespace {
+// OpType::SlowBuild / FastBuild: the whole structure from the current instance list.
+int full_build(SrScene* s) {
+    int rc;
     srh::flatten_instances(s->meshes, s->fid, s->world_tris);
     srh::BvhResult bvh;
     srh::build_bvh(s->world_tris, (uint32_t)srd::kMaxBinaryDepth, bvh);
@@ -398,26 +524,25 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     for (size_t i = 0; i < s->images.size(); i++) { textures[i].texels = (const uint32_t*)s->images[i].d_texels; textures[i].w = s->images[i].w; textures[i].h = s->images[i].h; }
     // device upload (synchronous, like the reference's scene-load BLAS build: blas.rs:178)
     HIP_TRY(hipDeviceSynchronize());
-    std::vector<srd::DevInstance> dinst(s->fid.instances.size() ? s->fid.instances.size() : 1);
-    memset(dinst.data(), 0, dinst.size() * sizeof(srd::DevInstance));
-    for (size_t i = 0; i < s->fid.instances.size(); i++) {
-        memcpy(dinst[i].w2o, s->fid.instances[i].w2o, 36);
-        const float* M = s->fid.instances[i].o2w.m;   // (float3x3)ObjectToWorld3x4
-        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) dinst[i].o2w[3 * r + c] = M[4 * r + c];
-    }
+    if ((rc = upload_instance_tables(s)) != SR_OK) return rc;
+    // inputs of later in-place updates: per-level node lists, exact node boxes (filled by the first refit), mesh table
+    std::vector<uint32_t> level_nodes;
+    srh::tree_levels(bvh.nodes, level_nodes, s->level_offsets);
+    if ((rc = s->d_level_nodes.upload(level_nodes.data(), level_nodes.size() * 4)) != SR_OK) return rc;
+    std::vector<float> node_box((size_t)bvh.n_nodes * 6, 0.0f);
+    if ((rc = s->d_node_box.upload(node_box.data(), node_box.size() * 4)) != SR_OK) return rc;
+    if ((rc = s->d_mesh_infos.upload(s->mesh_infos.data(), s->mesh_infos.size() * sizeof(SrMeshInfo))) != SR_OK) return rc;
+    s->shape.resize(s->fid.instances.size());
+    for (size_t i = 0; i < s->shape.size(); i++) s->shape[i] = s->fid.instances[i].mesh_slot;
     if ((rc = s->d_nodes.upload(bvh.nodes.data(), bvh.nodes.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_tris.upload(bvh.tris.data(), bvh.tris.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_shade.upload(shade.data(), shade.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_slot_of_gid.upload(slot_of_gid.data(), slot_of_gid.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_mesh_const.upload(mconst.data(), mconst.size() * sizeof(srd::DevMeshConst))) != SR_OK) return rc;
-    if ((rc = s->d_instances.upload(dinst.data(), dinst.size() * sizeof(srd::DevInstance))) != SR_OK) return rc;
     if ((rc = s->d_mesh_tex.upload(mtex.data(), mtex.size() * sizeof(srd::DevMeshTex))) != SR_OK) return rc;
     if ((rc = s->d_textures.upload(textures.data(), textures.size() * sizeof(srd::DevTexture))) != SR_OK) return rc;
     if (any_textured) { if ((rc = s->d_shade_tex.upload(shade_tex.data(), shade_tex.size() * 4)) != SR_OK) return rc; }
     else s->d_shade_tex.release();
-    std::vector<float> lights;
-    srh::light_table(s->fid, s->emissive_table, lights);
-    if ((rc = s->d_lights.upload(lights.data(), lights.size() * 4)) != SR_OK) return rc;
     s->dev.nodes = (const float4*)s->d_nodes.p;
     s->dev.tris = (const float4*)s->d_tris.p;
     s->dev.shade = (const float4*)s->d_shade.p;
@@ -426,12 +551,8 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     s->dev.mesh_tex = (const srd::DevMeshTex*)s->d_mesh_tex.p;
     s->dev.textures = (const srd::DevTexture*)s->d_textures.p;
     s->dev.slot_of_gid = (const uint32_t*)s->d_slot_of_gid.p;
-    s->dev.instances = (const srd::DevInstance*)s->d_instances.p;
-    s->dev.lights = (const srd::DevLight*)s->d_lights.p;
     s->dev.counters = (unsigned long long*)s->d_misc.p;
-    s->dev.num_lights = (uint32_t)s->fid.emissive_entries.size();
     s->dev.n_tris = s->fid.n_triangles;
-    s->dev.n_instances = (uint32_t)s->fid.instances.size();
     s->stats.n_triangles = s->fid.n_triangles;
     s->stats.n_nodes = bvh.n_nodes;
     s->stats.node_bytes = (uint64_t)bvh.n_nodes * 64;
@@ -444,6 +565,7 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     s->built = true;
     return SR_OK;
 }
+}  // namespace
 
 int sr_scene_get_tables(const SrScene* s, const SrTransform** transforms, uint32_t* n_instances,
                         const SrEmissiveIndirectionEntry** indirection, uint32_t* num_lights,

@@ -79,6 +79,15 @@ void flatten_instances(const std::vector<HostMesh>& meshes, const FrameInstanceD
 // 4-wide BVH (layout: traverse.h). max_stack = worst-case traversal stack entries for this tree.
 void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult& out);
 
+// Rebuild-vs-update heuristic of one acceleration structure (acceleration_structure/mod.rs:62-148), on the POD
+// state the C ABI exposes (SrAsState). Ops: SR_OP_*.
+void as_state_initial(uint32_t build_type, SrAsState* out);
+uint32_t as_state_next_op(const SrAsState& s, bool inputs_changed);
+void as_state_mark_built(SrAsState& s, uint32_t completed_op);
+// Breadth-first levels of a 4-wide tree (16 dwords per node, children at dwords 12..15): node indices sorted by depth,
+// deepest level first; level_offsets has n_levels + 1 entries.
+void tree_levels(const std::vector<uint32_t>& nodes, std::vector<uint32_t>& level_nodes, std::vector<uint32_t>& level_offsets);
+
 // the one thread-local error slot of the library (api.cpp); returns `code`
 int set_error(int code, const std::string& msg);
 }  // namespace srh

@@ -220,4 +220,53 @@ void light_table(const FrameInstanceData& fid, const std::vector<SrEmissiveTrian
     }
 }
 
+// ---- AsState (acceleration_structure/mod.rs:62-148) ------------------------------------------------------
+namespace {
+constexpr uint32_t kMaxUpdatesBeforeRebuild = 8;   // MAX_UPDATES_BEFORE_REBUILD
+constexpr uint32_t kFramesToSettle = 16;           // FRAMES_TO_SETTLE
+}
+
+void as_state_initial(uint32_t build_type, SrAsState* out) {
+    out->changing = build_type == SR_BUILD_RAPIDLY_CHANGING ? 1u : 0u;      // AsState::initial (:86-91)
+    out->frames_without_changes = 0;
+    out->number_of_updates_since_last_rebuild = 0;
+    out->_pad = 0;
+}
+
+uint32_t as_state_next_op(const SrAsState& s, bool inputs_changed) {           // AsState::next_op (:97-114)
+    if (!s.changing) return inputs_changed ? SR_OP_UPDATE : SR_OP_NONE;
+    if (inputs_changed) return s.number_of_updates_since_last_rebuild >= kMaxUpdatesBeforeRebuild ? SR_OP_FAST_BUILD : SR_OP_UPDATE;
+    return s.frames_without_changes + 1 >= kFramesToSettle ? SR_OP_SLOW_BUILD : SR_OP_NONE;
+}
+
+void as_state_mark_built(SrAsState& s, uint32_t completed) {                   // AsState::mark_built (:125-147)
+    switch (completed) {
+        case SR_OP_UPDATE:
+            if (s.changing) { s.number_of_updates_since_last_rebuild += 1; s.frames_without_changes = 0; }
+            else { s.changing = 1; s.frames_without_changes = 0; s.number_of_updates_since_last_rebuild = 1; }
+            break;
+        case SR_OP_FAST_BUILD: s.changing = 1; s.frames_without_changes = 0; s.number_of_updates_since_last_rebuild = 0; break;
+        case SR_OP_SLOW_BUILD: s.changing = 0; s.frames_without_changes = 0; s.number_of_updates_since_last_rebuild = 0; break;
+        default: if (s.changing) s.frames_without_changes += 1; break;
+    }
+}
+
+void tree_levels(const std::vector<uint32_t>& nodes, std::vector<uint32_t>& level_nodes, std::vector<uint32_t>& level_offsets) {
+    const uint32_t n = (uint32_t)(nodes.size() / 16);
+    std::vector<std::vector<uint32_t>> levels;
+    std::vector<uint32_t> cur{0u}, next;
+    while (!cur.empty() && n) {
+        levels.push_back(cur);
+        next.clear();
+        for (uint32_t node : cur)
+            for (int c = 0; c < 4; c++) { const int ref = (int)nodes[(size_t)node * 16 + 12 + c]; if (ref >= 0) next.push_back((uint32_t)ref); }
+        cur.swap(next);
+    }
+    level_nodes.clear(); level_offsets.assign(1, 0u);
+    for (size_t l = levels.size(); l-- > 0;) {
+        level_nodes.insert(level_nodes.end(), levels[l].begin(), levels[l].end());
+        level_offsets.push_back((uint32_t)level_nodes.size());
+    }
+}
+
 }  // namespace srh

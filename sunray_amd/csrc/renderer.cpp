@@ -172,8 +172,8 @@ int sr_renderer_render(SrRenderer* r, const float cam_pos[3], const float cam_ta
                        const uint32_t* counts, uint32_t n_keys, const SrTransform* transforms, void* stream, uint64_t* out_frame) {
     if (!r || !cam_pos || !cam_target) return rfail(SR_ERR_INVALID_ARG, "Renderer::render: null argument");
     R_HIP(hipSetDevice(r->device));
-    // instances: rebuild the acceleration structure only when the caller's list changed (the reference
-    // updates/rebuilds its TLAS every frame, tlas.rs:155-191)
+    // instances: the acceleration structure follows the caller's list — update in place / fast rebuild / settle as
+    // AsState decides (tlas.rs:155-191, acceleration_structure/mod.rs:62-148); an identical list is a quiet frame
     uint32_t n_xf = 0;
     for (uint32_t k = 0; k < n_keys; k++) n_xf += counts[k];
     const bool same = r->instances_valid && r->last_keys.size() == n_keys && r->last_transforms.size() == n_xf &&
@@ -186,6 +186,9 @@ int sr_renderer_render(SrRenderer* r, const float cam_pos[3], const float cam_ta
         r->last_counts.assign(counts, counts + n_keys);
         r->last_transforms.assign(transforms, transforms + n_xf);
         r->instances_valid = true;
+    } else {
+        int rc = sr_scene_end_frame(r->scene);      // quiet frame: the heuristic may settle with a quality rebuild
+        if (rc != SR_OK) return rc;
     }
     SrMatrices m;
     int rc = sr_camera_matrices(cam_pos, cam_target, fov_y, r->width, r->height, r->prev_view_proj, &m);   // lib.rs:1017-1048

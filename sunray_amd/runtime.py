@@ -189,6 +189,22 @@ class Scene:
             xf = np.zeros((1, 12), dtype=np.float32)
         check(lib().sr_scene_set_instances(self._h, _p(keys), _p(counts), C.c_uint32(len(keys)), _p(np.ascontiguousarray(xf))))
 
+    def end_frame(self):
+        check(lib().sr_scene_end_frame(self._h))
+
+    def as_state(self):
+        """-> (SrAsState, last op) of the scene's acceleration structure."""
+        st, op = abi.SrAsState(), C.c_uint32()
+        check(lib().sr_scene_as_state(self._h, C.byref(st), C.byref(op)))
+        return st, op.value
+
+    def read_bvh(self):
+        st = self.bvh_stats()
+        nodes = np.zeros((st.n_nodes, 16), dtype=np.uint32)
+        tris = np.zeros((max(st.n_triangles, 1), 12), dtype=np.float32)
+        check(lib().sr_scene_read_bvh(self._h, _p(nodes), _p(tris)))
+        return nodes, tris[:st.n_triangles]
+
     def load(self, desc):
         for img in desc.images:
             self.add_image(img)

@@ -537,6 +537,83 @@ def test_renderer_load_gltf_unload_reload(rt, oracle, tmp_path):
     r.close()
 
 
+# ---- acceleration-structure maintenance -------------------------------------------
+def _moving_instances(desc, f):
+    """Every instance orbits / spins / breathes a little differently each frame; scales stay non-uniform."""
+    out = []
+    for k, (key, xs) in enumerate(desc.instances):
+        moved = []
+        for j, x in enumerate(xs):
+            M = np.eye(4, dtype=np.float64); M[:3, :] = np.asarray(x, dtype=np.float64).reshape(3, 4)
+            a = 0.11 * f * (1 + (k + j) % 3)
+            R = np.array([[np.cos(a), 0, np.sin(a), 0.02 * f * ((k % 3) - 1)], [0, 1 + 0.01 * f * (k % 2), 0, 0.01 * f], [-np.sin(a), 0, np.cos(a), 0], [0, 0, 0, 1]])
+            moved.append((R @ M)[:3, :].astype(np.float32).reshape(12) if key >= 7 else np.asarray(x, dtype=np.float32))
+        out.append((key, moved))
+    return out
+
+
+def test_dynamic_instances_update_in_place_and_rebuild_cycle(rt, oracle, blue_noise):
+    """The instance transforms change every frame: the scene follows AsState (8 in-place updates = device re-flatten +
+    refit, then a fast rebuild), and every frame's queries and passes still equal the oracle, which rebuilds its own
+    BVH from scratch each time. The refitted tree read back from the device is a valid conservative BVH."""
+    from test_host_abi import _check_bvh
+    desc = scenes.cornell_glass_mirror()
+    W, H = 96, 72
+    osc, gsc = oracle.OracleScene().load(desc), rt.Scene(0).load(desc)
+    of, gf = oracle.HostFrame(W, H, blue_noise), rt.DeviceFrame(W, H, blue_noise)
+    rays = np.concatenate([camera_rays(oracle, desc, 64, 64), random_rays(6000, 77)])
+    rays_t = rt.rays_to_device(rays)
+    ops, prev = [gsc.as_state()[1]], None
+    stats0 = gsc.bvh_stats()
+    for f in range(1, 12):
+        inst = _moving_instances(desc, f)
+        osc.set_instances(inst); gsc.set_instances(inst)
+        ops.append(gsc.as_state()[1])
+        assert_bits_equal(osc.trace_closest(rays), rt.hits_from_device(gsc.trace_closest(rays_t, len(rays))), "SrHit f%d" % f)
+        assert np.array_equal(osc.trace_any(rays), gsc.trace_any(rays_t, len(rays)).cpu().numpy().view(np.uint32)), "occluded f%d" % f
+        om = oracle.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, prev)
+        gm = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, prev)
+        prev = list(om.view_proj)
+        osc.trace_ris(of, om, f - 1); osc.trace_final(of, om, f - 1)
+        gsc.trace_ris(gf, gm, f - 1); gsc.trace_final(gf, gm, f - 1)
+        h = gf.host()
+        assert_bits_equal(of.raw_color, h["raw_color"], "raw_color f%d" % f)
+        assert_bits_equal(of.reservoirs[(f - 1) & 1], h["reservoirs"][(f - 1) & 1], "reservoir f%d" % f)
+        if f in (3, 8):
+            nodes, tris = gsc.read_bvh()
+            st = gsc.bvh_stats()
+            assert st.n_nodes == stats0.n_nodes                                   # topology kept by updates
+            _check_bvh(nodes, tris, st.max_depth, st.max_stack)
+    U, F, S = abi.OP_UPDATE, abi.OP_FAST_BUILD, abi.OP_SLOW_BUILD
+    assert ops == [S] + [U] * 8 + [F] + [U] * 2
+    # a different instance LAYOUT cannot be updated in place -> rebuild
+    gsc.set_instances(_moving_instances(desc, 12)[:-1])
+    assert gsc.as_state()[1] == F
+    # quiet frames: 15 idle, then the settle rebuild (SlowBuild), then Optimal
+    quiet = []
+    for _ in range(17):
+        gsc.end_frame(); quiet.append(gsc.as_state()[1])
+    assert quiet == [abi.OP_NONE] * 15 + [S] + [abi.OP_NONE] and gsc.as_state()[0].changing == 0
+
+
+def test_update_in_place_large_scene_timing(rt, oracle):
+    """1M-triangle scene + a moving light rig: an in-place update must be far cheaper than the host rebuild and give
+    the same hits as the oracle."""
+    desc = scenes.heightfield(708)
+    osc, gsc = oracle.OracleScene().load(desc), rt.Scene(0).load(desc)
+    build_ms = gsc.bvh_stats().build_ms
+    inst = [(k, [np.asarray(x, dtype=np.float32) + (np.float32(0.3) * np.eye(3, 4, 3, dtype=np.float32).reshape(12) if k == 2 else 0) for x in xs])
+            for k, xs in desc.instances]
+    gsc.set_instances(inst); osc.set_instances(inst)
+    st, op = gsc.as_state()
+    assert op == abi.OP_UPDATE
+    update_ms = gsc.bvh_stats().build_ms
+    print("host build %.1f ms, in-place update %.2f ms" % (build_ms, update_ms))
+    assert update_ms < 0.25 * build_ms
+    rays = camera_rays(oracle, desc, 256, 144)
+    assert_bits_equal(osc.trace_closest(rays), rt.hits_from_device(gsc.trace_closest(rt.rays_to_device(rays), len(rays))), "SrHit after update")
+
+
 # ---- BASELINE.json full sizes ---------------------------------------------------------------------
 def test_full_size_1m_triangles_1080p(rt, oracle, blue_noise):
     """The bench workload itself (1920x1080, 999 714 triangles, reference constants): the oracle is fast

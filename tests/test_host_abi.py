@@ -197,6 +197,61 @@ def test_renderer_argument_errors_and_no_gpu_failure():
         assert e.value.code == -2
 
 
+class AsStateRef:
+    """acceleration_structure/mod.rs:62-148 restated in Python (MAX_UPDATES_BEFORE_REBUILD = 8, FRAMES_TO_SETTLE = 16)."""
+
+    def __init__(self, build_type):
+        self.changing = build_type == abi.BUILD_RAPIDLY_CHANGING
+        self.quiet = self.updates = 0
+
+    def next_op(self, changed):
+        if not self.changing:
+            return abi.OP_UPDATE if changed else abi.OP_NONE
+        if changed:
+            return abi.OP_FAST_BUILD if self.updates >= 8 else abi.OP_UPDATE
+        return abi.OP_SLOW_BUILD if self.quiet + 1 >= 16 else abi.OP_NONE
+
+    def mark_built(self, op):
+        if op == abi.OP_UPDATE:
+            if self.changing:
+                self.updates += 1; self.quiet = 0
+            else:
+                self.changing, self.quiet, self.updates = True, 0, 1
+        elif op == abi.OP_FAST_BUILD:
+            self.changing, self.quiet, self.updates = True, 0, 0
+        elif op == abi.OP_SLOW_BUILD:
+            self.changing, self.quiet, self.updates = False, 0, 0
+        elif self.changing:
+            self.quiet += 1
+
+
+def test_as_state_heuristic_matches_restatement_and_documented_behaviour():
+    L = _lib.lib()
+    rng = np.random.default_rng(4)
+    for build_type in (abi.BUILD_RAPIDLY_CHANGING, abi.BUILD_SOMETIMES_CHANGES, abi.BUILD_STATIC):
+        st, ref = abi.SrAsState(), AsStateRef(build_type)
+        L.sr_as_state_initial(build_type, C.byref(st))
+        for changed in rng.random(600) < np.repeat(rng.random(30), 20):          # bursts of activity and quiet stretches
+            op = L.sr_as_state_next_op(C.byref(st), int(changed))
+            assert op == ref.next_op(bool(changed))
+            L.sr_as_state_mark_built(C.byref(st), op)
+            ref.mark_built(op)
+            assert (st.changing, st.frames_without_changes, st.number_of_updates_since_last_rebuild) == (int(ref.changing), ref.quiet, ref.updates)
+    # the documented cycle for a structure that changes every frame: 8 updates, then a fast rebuild, repeat
+    st = abi.SrAsState()
+    L.sr_as_state_initial(abi.BUILD_SOMETIMES_CHANGES, C.byref(st))
+    ops = []
+    for _ in range(20):
+        op = L.sr_as_state_next_op(C.byref(st), 1); L.sr_as_state_mark_built(C.byref(st), op); ops.append(op)
+    U, F, S, N = abi.OP_UPDATE, abi.OP_FAST_BUILD, abi.OP_SLOW_BUILD, abi.OP_NONE
+    assert ops == [U] * 8 + [F] + [U] * 8 + [F] + [U] * 2
+    # then quiet: 15 idle frames, the 16th settles with a quality rebuild, afterwards nothing
+    ops = []
+    for _ in range(18):
+        op = L.sr_as_state_next_op(C.byref(st), 0); L.sr_as_state_mark_built(C.byref(st), op); ops.append(op)
+    assert ops == [N] * 15 + [S] + [N] * 2 and st.changing == 0
+
+
 def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     monkeypatch.setattr(_lib, "_lib", None)
