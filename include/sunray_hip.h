@@ -326,6 +326,10 @@ int sr_scene_as_state(const SrScene* scene, SrAsState* state, uint32_t* last_op)
  * inputs_changed = false): advances the quiet-frame counter and, when AsState asks for it, performs the quality
  * rebuild. The Renderer facade calls it for every frame that skips sr_scene_set_instances. */
 int sr_scene_end_frame(SrScene* scene);
+/* Test / bench hook: the next sr_scene_set_instances performs `op` (SR_OP_SLOW_BUILD = host binned-SAH build,
+ * SR_OP_FAST_BUILD = device LBVH build, SR_OP_UPDATE = in-place update if the layout allows) instead of the
+ * heuristic's choice. The heuristic state is still advanced with the op performed. */
+int sr_scene_force_next_op(SrScene* scene, uint32_t op);
 /* Debug read-back of the device tree: n_nodes x 16 dwords, n_triangles x 12 floats (either may be NULL). */
 int sr_scene_read_bvh(const SrScene* scene, uint32_t* nodes_out, float* tris_out);
 

@@ -52,6 +52,15 @@ struct DeviceBuffer {
         if (n) HIP_TRY(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
         return SR_OK;
     }
+    int reserve(size_t n) {
+        if (n > bytes || p == nullptr) {
+            if (p) (void)hipFree(p);
+            p = nullptr; bytes = 0;
+            HIP_TRY(hipMalloc(&p, n ? n : 16));
+            bytes = n ? n : 16;
+        }
+        return SR_OK;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
@@ -73,7 +82,9 @@ struct SrScene {
     DeviceBuffer d_nodes, d_tris, d_shade, d_mesh_const, d_slot_of_gid, d_instances, d_lights, d_misc;
     DeviceBuffer d_shade_tex, d_mesh_tex, d_textures;
     // acceleration-structure maintenance (update in place): per-level node lists, exact node boxes, flatten inputs
-    DeviceBuffer d_level_nodes, d_node_box, d_mesh_infos, d_flat_instances;
+    DeviceBuffer d_level_nodes, d_node_box, d_mesh_infos, d_flat_instances, d_scratch;
+    uint32_t forced_op = SR_OP_NONE;        // sr_scene_force_next_op (test / bench hook)
+    bool last_build_on_device = false;
     std::vector<uint32_t> level_offsets;
     std::vector<uint32_t> shape;            // mesh slot of every instance of the built tree: an UPDATE needs the same layout
     SrAsState as_state{0, 0, 0, 0};         // SometimesChanges -> Optimal (resource_manager.rs:119-126, mod.rs:86-91)
@@ -190,7 +201,7 @@ int sr_scene_destroy(SrScene* s) {
     for (auto& m : s->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (auto& im : s->images) if (im.d_texels) (void)hipFree(im.d_texels);
     s->d_shade_tex.release(); s->d_mesh_tex.release(); s->d_textures.release();
-    s->d_level_nodes.release(); s->d_node_box.release(); s->d_mesh_infos.release(); s->d_flat_instances.release();
+    s->d_level_nodes.release(); s->d_node_box.release(); s->d_mesh_infos.release(); s->d_flat_instances.release(); s->d_scratch.release();
     s->d_nodes.release(); s->d_tris.release(); s->d_shade.release(); s->d_mesh_const.release(); s->d_slot_of_gid.release(); s->d_instances.release();
     s->d_lights.release(); s->d_misc.release();
     for (auto& pool : s->events) for (auto& e : pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -354,118 +365,9 @@ int upload_instance_tables(SrScene* s) {
     return SR_OK;
 }
 
-// OpType::Update: same instance layout, new transforms. The triangles are re-flattened on the device into their
-// existing leaf slots and the quantised nodes are refitted bottom-up; topology, shade records and mesh tables stay.
-int update_in_place(SrScene* s) {
-    const auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(hipDeviceSynchronize());
-    int rc = upload_instance_tables(s);
-    if (rc != SR_OK) return rc;
-    int e = srk_launch_flatten_slots((float4*)s->d_tris.p, (const float4*)s->d_shade.p, (const SrMeshInfo*)s->d_mesh_infos.p,
-                                     (const srd::FlatInstance*)s->d_flat_instances.p, s->fid.n_triangles, nullptr);
-    if (e != 0) return fail(SR_ERR_HIP, std::string("flatten launch failed: ") + hipGetErrorString((hipError_t)e));
-    e = srk_launch_refit((uint32_t*)s->d_nodes.p, (const float4*)s->d_tris.p, (float*)s->d_node_box.p, (const uint32_t*)s->d_level_nodes.p,
-                         s->level_offsets.data(), (uint32_t)s->level_offsets.size() - 1, nullptr);
-    if (e != 0) return fail(SR_ERR_HIP, std::string("refit launch failed: ") + hipGetErrorString((hipError_t)e));
-    HIP_TRY(hipDeviceSynchronize());
-    s->stats.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return SR_OK;
-}
-
-int full_build(SrScene* s);
-
-}  // namespace
-
-int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* counts, uint32_t n_keys, const SrTransform* transforms) {
-    if (!s || (n_keys && (!keys || !counts))) return fail(SR_ERR_INVALID_ARG, "frame_instance_data: null argument");
-    int rc = bind_device(s);
-    if (rc != SR_OK) return rc;
-    std::string err;
-    srh::FrameInstanceData fid;
-    if (!srh::frame_instance_data(s->meshes, s->slots, keys, counts, n_keys, transforms, fid, err)) return fail(SR_ERR_INVALID_ARG, err);
-    if (fid.n_triangles >= (1u << 28)) return fail(SR_ERR_UNSUPPORTED, "scene exceeds 2^28 triangles (leaf reference encoding)");
-    s->fid = std::move(fid);
-    s->emissive_table = s->emissive_tris;
-    if (s->emissive_table.empty()) { SrEmissiveTriangle z; memset(&z, 0, sizeof(z)); s->emissive_table.push_back(z); }
-    uint32_t n_xf = 0;
-    for (uint32_t k = 0; k < n_keys; k++) n_xf += counts[k];
-    s->last_keys.assign(keys, keys + n_keys); s->last_counts.assign(counts, counts + n_keys);
-    s->last_transforms.assign(transforms, transforms + n_xf);
-    // Tlas::queue_build (tlas.rs:155-191): the instance data is new, so the heuristic is asked with inputs_changed =
-    // true; an UPDATE needs the same instance layout (here: the same mesh per instance and unchanged meshes),
-    // anything else is a rebuild. The very first build is the quality build (Tlas::new).
-    bool can_update = s->built && s->shape.size() == s->fid.instances.size() && s->fid.n_triangles > 0;
-    for (size_t i = 0; can_update && i < s->shape.size(); i++) can_update = s->shape[i] == s->fid.instances[i].mesh_slot;
-    uint32_t op;
-    if (!s->built_once) op = SR_OP_SLOW_BUILD;
-    else {
-        op = srh::as_state_next_op(s->as_state, true);
-        if (op == SR_OP_UPDATE && !can_update) op = SR_OP_FAST_BUILD;
-    }
-    rc = op == SR_OP_UPDATE ? update_in_place(s) : full_build(s);
-    if (rc != SR_OK) { s->built = false; return rc; }
-    if (s->built_once) srh::as_state_mark_built(s->as_state, op);
-    s->built_once = true;
-    s->last_op = op;
-    return SR_OK;
-}
-
-int sr_scene_end_frame(SrScene* s) {
-    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_end_frame: scene is null");
-    if (!s->built) { s->last_op = SR_OP_NONE; return SR_OK; }
-    const uint32_t op = srh::as_state_next_op(s->as_state, false);
-    if (op == SR_OP_SLOW_BUILD) {
-        int rc = bind_device(s);
-        if (rc != SR_OK) return rc;
-        if ((rc = full_build(s)) != SR_OK) { s->built = false; return rc; }
-    }
-    srh::as_state_mark_built(s->as_state, op);
-    s->last_op = op;
-    return SR_OK;
-}
-
-int sr_scene_as_state(const SrScene* s, SrAsState* state, uint32_t* last_op) {
-    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_as_state: scene is null");
-    if (state) *state = s->as_state;
-    if (last_op) *last_op = s->last_op;
-    return SR_OK;
-}
-
-void sr_as_state_initial(uint32_t build_type, SrAsState* out) { if (out) srh::as_state_initial(build_type, out); }
-uint32_t sr_as_state_next_op(const SrAsState* state, int inputs_changed) { return state ? srh::as_state_next_op(*state, inputs_changed != 0) : SR_OP_NONE; }
-void sr_as_state_mark_built(SrAsState* state, uint32_t completed_op) { if (state) srh::as_state_mark_built(*state, completed_op); }
-
-int sr_scene_read_bvh(const SrScene* s, uint32_t* nodes_out, float* tris_out) {
-    if (!s || !s->built) return fail(SR_ERR_STATE, "sr_scene_read_bvh: scene not built");
-    HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipDeviceSynchronize());
-    if (nodes_out) HIP_TRY(hipMemcpy(nodes_out, s->d_nodes.p, (size_t)s->stats.n_nodes * 64, hipMemcpyDeviceToHost));
-    if (tris_out && s->fid.n_triangles) HIP_TRY(hipMemcpy(tris_out, s->d_tris.p, (size_t)s->fid.n_triangles * 48, hipMemcpyDeviceToHost));
-    return SR_OK;
-}
-
-namespace {
-// OpType::SlowBuild / FastBuild: the whole structure from the current instance list.
-int full_build(SrScene* s) {
+// Per-mesh payload constants, the texture side of the materials and the image table (independent of the tree).
+int upload_mesh_tables(SrScene* s, bool* any_textured_out) {
     int rc;
-    srh::flatten_instances(s->meshes, s->fid, s->world_tris);
-    srh::BvhResult bvh;
-    srh::build_bvh(s->world_tris, (uint32_t)srd::kMaxBinaryDepth, bvh);
-    if (bvh.max_stack > (uint32_t)srd::kStackMax) return fail(SR_ERR_STATE, "BVH needs a deeper traversal stack than the kernels provide");
-    // shade records (object-space vertex normals + instance + mesh slot) in leaf order, slot lookup
-    const uint32_t n_tris = s->fid.n_triangles;
-    std::vector<float> shade((size_t)n_tris * 12, 0.0f);
-    std::vector<uint32_t> slot_of_gid(n_tris ? n_tris : 1, 0u);
-    for (uint32_t slot = 0; slot < n_tris; slot++) {
-        const srh::BuildTri& t = s->world_tris[bvh.order[slot]];
-        const srh::HostInstance& inst = s->fid.instances[t.inst];
-        const srh::HostMesh& mesh = s->meshes[inst.mesh_slot];
-        float* q = &shade[(size_t)slot * 12];
-        for (int j = 0; j < 3; j++) memcpy(q + 3 * j, mesh.vertices[mesh.indices[3 * t.prim + j]].normal, 12);
-        memcpy(q + 9, &t.inst, 4);
-        memcpy(q + 10, &inst.mesh_slot, 4);
-        slot_of_gid[t.gid] = slot;
-    }
     std::vector<srd::DevMeshConst> mconst(s->meshes.size() ? s->meshes.size() : 1);
     memset(mconst.data(), 0, mconst.size() * sizeof(srd::DevMeshConst));
     for (size_t i = 0; i < s->meshes.size(); i++) {
@@ -500,6 +402,205 @@ int full_build(SrScene* s) {
         mconst[i].textured = (t.img_base != SR_NULL_TEXTURE || t.img_mr != SR_NULL_TEXTURE || t.img_normal != SR_NULL_TEXTURE || t.img_emissive != SR_NULL_TEXTURE) ? 1u : 0u;
         any_textured = any_textured || mconst[i].textured;
     }
+    std::vector<srd::DevTexture> textures(s->images.size() ? s->images.size() : 1);
+    memset(textures.data(), 0, textures.size() * sizeof(srd::DevTexture));
+    for (size_t i = 0; i < s->images.size(); i++) { textures[i].texels = (const uint32_t*)s->images[i].d_texels; textures[i].w = s->images[i].w; textures[i].h = s->images[i].h; }
+    if ((rc = s->d_mesh_const.upload(mconst.data(), mconst.size() * sizeof(srd::DevMeshConst))) != SR_OK) return rc;
+    if ((rc = s->d_mesh_tex.upload(mtex.data(), mtex.size() * sizeof(srd::DevMeshTex))) != SR_OK) return rc;
+    if ((rc = s->d_textures.upload(textures.data(), textures.size() * sizeof(srd::DevTexture))) != SR_OK) return rc;
+    s->dev.mesh_const = (const srd::DevMeshConst*)s->d_mesh_const.p;
+    s->dev.mesh_tex = (const srd::DevMeshTex*)s->d_mesh_tex.p;
+    s->dev.textures = (const srd::DevTexture*)s->d_textures.p;
+    *any_textured_out = any_textured;
+    return SR_OK;
+}
+
+// OpType::Update: same instance layout, new transforms. The triangles are re-flattened on the device into their
+// existing leaf slots and the quantised nodes are refitted bottom-up; topology, shade records and mesh tables stay.
+int update_in_place(SrScene* s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipDeviceSynchronize());
+    int rc = upload_instance_tables(s);
+    if (rc != SR_OK) return rc;
+    int e = srk_launch_flatten_slots((float4*)s->d_tris.p, (const float4*)s->d_shade.p, (const SrMeshInfo*)s->d_mesh_infos.p,
+                                     (const srd::FlatInstance*)s->d_flat_instances.p, s->fid.n_triangles, nullptr);
+    if (e != 0) return fail(SR_ERR_HIP, std::string("flatten launch failed: ") + hipGetErrorString((hipError_t)e));
+    e = srk_launch_refit((uint32_t*)s->d_nodes.p, (const float4*)s->d_tris.p, (float*)s->d_node_box.p, (const uint32_t*)s->d_level_nodes.p,
+                         s->level_offsets.data(), (uint32_t)s->level_offsets.size() - 1, nullptr);
+    if (e != 0) return fail(SR_ERR_HIP, std::string("refit launch failed: ") + hipGetErrorString((hipError_t)e));
+    HIP_TRY(hipDeviceSynchronize());
+    s->stats.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SR_OK;
+}
+
+int full_build(SrScene* s);
+
+// OpType::FastBuild: linear BVH built on the device (bvh_gpu.hip). Falls back to the host builder for small scenes
+// and for trees that would need a deeper traversal stack than one workgroup's LDS share.
+constexpr uint32_t kDeviceBuildMinTris = 4096;
+constexpr uint32_t kDeviceStackCap = 48;
+int fast_build(SrScene* s) {
+    const uint32_t n = s->fid.n_triangles;
+    if (n < kDeviceBuildMinTris) return full_build(s);
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    HIP_TRY(hipDeviceSynchronize());
+    bool any_textured = false;
+    if ((rc = upload_mesh_tables(s, &any_textured)) != SR_OK) return rc;
+    if ((rc = upload_instance_tables(s)) != SR_OK) return rc;
+    if ((rc = s->d_mesh_infos.upload(s->mesh_infos.data(), s->mesh_infos.size() * sizeof(SrMeshInfo))) != SR_OK) return rc;
+    const uint32_t node_cap = n / 2 + 1024;
+    if ((rc = s->d_nodes.reserve((size_t)node_cap * 64)) != SR_OK || (rc = s->d_node_box.reserve((size_t)node_cap * 24)) != SR_OK ||
+        (rc = s->d_tris.reserve((size_t)n * 48)) != SR_OK || (rc = s->d_shade.reserve((size_t)n * 48)) != SR_OK ||
+        (rc = s->d_slot_of_gid.reserve((size_t)n * 4)) != SR_OK) return rc;
+    if (any_textured) { if ((rc = s->d_shade_tex.reserve((size_t)n * 96)) != SR_OK) return rc; }
+    else s->d_shade_tex.release();
+    const size_t scratch = srk_lbvh_scratch_bytes(n, node_cap);
+    if ((rc = s->d_scratch.reserve(scratch)) != SR_OK) return rc;
+    LbvhArgs a;
+    a.meshes = (const SrMeshInfo*)s->d_mesh_infos.p; a.instances = (const srd::FlatInstance*)s->d_flat_instances.p;
+    a.n_instances = (uint32_t)s->fid.instances.size(); a.n_tris = n;
+    a.nodes = (float4*)s->d_nodes.p; a.node_cap = node_cap;
+    a.tris = (float4*)s->d_tris.p; a.shade = (float4*)s->d_shade.p; a.shade_tex = (float4*)s->d_shade_tex.p;
+    a.slot_of_gid = (uint32_t*)s->d_slot_of_gid.p; a.node_box = (float*)s->d_node_box.p;
+    a.scratch = s->d_scratch.p; a.scratch_bytes = s->d_scratch.bytes;
+    a.stack_floor = (uint32_t)srd::kStackMax; a.stack_cap = kDeviceStackCap;
+    LbvhResult r;
+    const int e = srk_lbvh_build(a, &r, nullptr);
+    if (e > 0) return fail(SR_ERR_HIP, std::string("device BVH build failed: ") + hipGetErrorString((hipError_t)e));
+    if (e < 0) return full_build(s);                      // tree outside the limits: quality build on the host instead
+    std::vector<uint32_t> level_nodes;
+    s->level_offsets.assign(1, 0u);
+    for (size_t l = r.level_ranges.size(); l-- > 0;) {
+        for (uint32_t k = 0; k < r.level_ranges[l].second; k++) level_nodes.push_back(r.level_ranges[l].first + k);
+        s->level_offsets.push_back((uint32_t)level_nodes.size());
+    }
+    if ((rc = s->d_level_nodes.upload(level_nodes.data(), level_nodes.size() * 4)) != SR_OK) return rc;
+    s->shape.resize(s->fid.instances.size());
+    for (size_t i = 0; i < s->shape.size(); i++) s->shape[i] = s->fid.instances[i].mesh_slot;
+    s->dev.nodes = (const float4*)s->d_nodes.p;
+    s->dev.tris = (const float4*)s->d_tris.p;
+    s->dev.shade = (const float4*)s->d_shade.p;
+    s->dev.shade_tex = (const float4*)s->d_shade_tex.p;
+    s->dev.slot_of_gid = (const uint32_t*)s->d_slot_of_gid.p;
+    s->dev.counters = (unsigned long long*)s->d_misc.p;
+    s->dev.n_tris = n;
+    s->stats.n_triangles = n;
+    s->stats.n_nodes = r.n_nodes;
+    s->stats.node_bytes = (uint64_t)r.n_nodes * 64;
+    s->stats.tri_bytes = (uint64_t)n * 48;
+    s->stats.max_depth = r.max_depth;
+    s->stats.max_stack = r.max_stack;
+    s->stack_entries = (int)((std::max(r.max_stack, 4u) + 3u) & ~3u);
+    s->stats.sah_cost = 0.0f;
+    s->stats.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    s->built = true;
+    s->last_build_on_device = true;
+    return SR_OK;
+}
+
+}  // namespace
+
+int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* counts, uint32_t n_keys, const SrTransform* transforms) {
+    if (!s || (n_keys && (!keys || !counts))) return fail(SR_ERR_INVALID_ARG, "frame_instance_data: null argument");
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    std::string err;
+    srh::FrameInstanceData fid;
+    if (!srh::frame_instance_data(s->meshes, s->slots, keys, counts, n_keys, transforms, fid, err)) return fail(SR_ERR_INVALID_ARG, err);
+    if (fid.n_triangles >= (1u << 28)) return fail(SR_ERR_UNSUPPORTED, "scene exceeds 2^28 triangles (leaf reference encoding)");
+    s->fid = std::move(fid);
+    s->emissive_table = s->emissive_tris;
+    if (s->emissive_table.empty()) { SrEmissiveTriangle z; memset(&z, 0, sizeof(z)); s->emissive_table.push_back(z); }
+    uint32_t n_xf = 0;
+    for (uint32_t k = 0; k < n_keys; k++) n_xf += counts[k];
+    s->last_keys.assign(keys, keys + n_keys); s->last_counts.assign(counts, counts + n_keys);
+    s->last_transforms.assign(transforms, transforms + n_xf);
+    // Tlas::queue_build (tlas.rs:155-191): the instance data is new, so the heuristic is asked with inputs_changed =
+    // true; an UPDATE needs the same instance layout (here: the same mesh per instance and unchanged meshes),
+    // anything else is a rebuild. The very first build is the quality build (Tlas::new).
+    bool can_update = s->built && s->shape.size() == s->fid.instances.size() && s->fid.n_triangles > 0;
+    for (size_t i = 0; can_update && i < s->shape.size(); i++) can_update = s->shape[i] == s->fid.instances[i].mesh_slot;
+    uint32_t op;
+    if (!s->built_once) op = SR_OP_SLOW_BUILD;
+    else {
+        op = srh::as_state_next_op(s->as_state, true);
+        if (op == SR_OP_UPDATE && !can_update) op = SR_OP_FAST_BUILD;
+    }
+    if (s->forced_op != SR_OP_NONE) { op = (s->forced_op == SR_OP_UPDATE && !can_update) ? SR_OP_FAST_BUILD : s->forced_op; s->forced_op = SR_OP_NONE; }
+    rc = op == SR_OP_UPDATE ? update_in_place(s) : op == SR_OP_FAST_BUILD ? fast_build(s) : full_build(s);
+    if (rc != SR_OK) { s->built = false; return rc; }
+    if (s->built_once) srh::as_state_mark_built(s->as_state, op);
+    s->built_once = true;
+    s->last_op = op;
+    return SR_OK;
+}
+
+int sr_scene_end_frame(SrScene* s) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_end_frame: scene is null");
+    if (!s->built) { s->last_op = SR_OP_NONE; return SR_OK; }
+    const uint32_t op = srh::as_state_next_op(s->as_state, false);
+    if (op == SR_OP_SLOW_BUILD) {
+        int rc = bind_device(s);
+        if (rc != SR_OK) return rc;
+        if ((rc = full_build(s)) != SR_OK) { s->built = false; return rc; }
+    }
+    srh::as_state_mark_built(s->as_state, op);
+    s->last_op = op;
+    return SR_OK;
+}
+
+int sr_scene_force_next_op(SrScene* s, uint32_t op) {
+    if (!s || op > SR_OP_UPDATE) return fail(SR_ERR_INVALID_ARG, "sr_scene_force_next_op: bad argument");
+    s->forced_op = op;
+    return SR_OK;
+}
+
+int sr_scene_as_state(const SrScene* s, SrAsState* state, uint32_t* last_op) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_as_state: scene is null");
+    if (state) *state = s->as_state;
+    if (last_op) *last_op = s->last_op;
+    return SR_OK;
+}
+
+void sr_as_state_initial(uint32_t build_type, SrAsState* out) { if (out) srh::as_state_initial(build_type, out); }
+uint32_t sr_as_state_next_op(const SrAsState* state, int inputs_changed) { return state ? srh::as_state_next_op(*state, inputs_changed != 0) : SR_OP_NONE; }
+void sr_as_state_mark_built(SrAsState* state, uint32_t completed_op) { if (state) srh::as_state_mark_built(*state, completed_op); }
+
+int sr_scene_read_bvh(const SrScene* s, uint32_t* nodes_out, float* tris_out) {
+    if (!s || !s->built) return fail(SR_ERR_STATE, "sr_scene_read_bvh: scene not built");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (nodes_out) HIP_TRY(hipMemcpy(nodes_out, s->d_nodes.p, (size_t)s->stats.n_nodes * 64, hipMemcpyDeviceToHost));
+    if (tris_out && s->fid.n_triangles) HIP_TRY(hipMemcpy(tris_out, s->d_tris.p, (size_t)s->fid.n_triangles * 48, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+namespace {
+// OpType::SlowBuild / FastBuild: the whole structure from the current instance list.
+int full_build(SrScene* s) {
+    int rc;
+    HIP_TRY(hipDeviceSynchronize());
+    srh::flatten_instances(s->meshes, s->fid, s->world_tris);
+    srh::BvhResult bvh;
+    srh::build_bvh(s->world_tris, (uint32_t)srd::kMaxBinaryDepth, bvh);
+    if (bvh.max_stack > (uint32_t)srd::kStackMax) return fail(SR_ERR_STATE, "BVH needs a deeper traversal stack than the kernels provide");
+    // shade records (object-space vertex normals + instance + mesh slot) in leaf order, slot lookup
+    const uint32_t n_tris = s->fid.n_triangles;
+    std::vector<float> shade((size_t)n_tris * 12, 0.0f);
+    std::vector<uint32_t> slot_of_gid(n_tris ? n_tris : 1, 0u);
+    for (uint32_t slot = 0; slot < n_tris; slot++) {
+        const srh::BuildTri& t = s->world_tris[bvh.order[slot]];
+        const srh::HostInstance& inst = s->fid.instances[t.inst];
+        const srh::HostMesh& mesh = s->meshes[inst.mesh_slot];
+        float* q = &shade[(size_t)slot * 12];
+        for (int j = 0; j < 3; j++) memcpy(q + 3 * j, mesh.vertices[mesh.indices[3 * t.prim + j]].normal, 12);
+        memcpy(q + 9, &t.inst, 4);
+        memcpy(q + 10, &inst.mesh_slot, 4);
+        slot_of_gid[t.gid] = slot;
+    }
+    bool any_textured = false;
+    if ((rc = upload_mesh_tables(s, &any_textured)) != SR_OK) return rc;
     std::vector<float> shade_tex;
     if (any_textured) {
         shade_tex.assign((size_t)n_tris * 24, 0.0f);
@@ -519,9 +620,6 @@ int full_build(SrScene* s) {
             memcpy(q + 19, v[2]->tangent, 12);
         }
     }
-    std::vector<srd::DevTexture> textures(s->images.size() ? s->images.size() : 1);
-    memset(textures.data(), 0, textures.size() * sizeof(srd::DevTexture));
-    for (size_t i = 0; i < s->images.size(); i++) { textures[i].texels = (const uint32_t*)s->images[i].d_texels; textures[i].w = s->images[i].w; textures[i].h = s->images[i].h; }
     // device upload (synchronous, like the reference's scene-load BLAS build: blas.rs:178)
     HIP_TRY(hipDeviceSynchronize());
     if ((rc = upload_instance_tables(s)) != SR_OK) return rc;
@@ -538,18 +636,12 @@ int full_build(SrScene* s) {
     if ((rc = s->d_tris.upload(bvh.tris.data(), bvh.tris.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_shade.upload(shade.data(), shade.size() * 4)) != SR_OK) return rc;
     if ((rc = s->d_slot_of_gid.upload(slot_of_gid.data(), slot_of_gid.size() * 4)) != SR_OK) return rc;
-    if ((rc = s->d_mesh_const.upload(mconst.data(), mconst.size() * sizeof(srd::DevMeshConst))) != SR_OK) return rc;
-    if ((rc = s->d_mesh_tex.upload(mtex.data(), mtex.size() * sizeof(srd::DevMeshTex))) != SR_OK) return rc;
-    if ((rc = s->d_textures.upload(textures.data(), textures.size() * sizeof(srd::DevTexture))) != SR_OK) return rc;
     if (any_textured) { if ((rc = s->d_shade_tex.upload(shade_tex.data(), shade_tex.size() * 4)) != SR_OK) return rc; }
     else s->d_shade_tex.release();
     s->dev.nodes = (const float4*)s->d_nodes.p;
     s->dev.tris = (const float4*)s->d_tris.p;
     s->dev.shade = (const float4*)s->d_shade.p;
-    s->dev.mesh_const = (const srd::DevMeshConst*)s->d_mesh_const.p;
     s->dev.shade_tex = (const float4*)s->d_shade_tex.p;
-    s->dev.mesh_tex = (const srd::DevMeshTex*)s->d_mesh_tex.p;
-    s->dev.textures = (const srd::DevTexture*)s->d_textures.p;
     s->dev.slot_of_gid = (const uint32_t*)s->d_slot_of_gid.p;
     s->dev.counters = (unsigned long long*)s->d_misc.p;
     s->dev.n_tris = s->fid.n_triangles;
@@ -563,6 +655,7 @@ int full_build(SrScene* s) {
     s->stats.sah_cost = bvh.sah_cost;
     s->stats.build_ms = bvh.build_ms;
     s->built = true;
+    s->last_build_on_device = false;
     return SR_OK;
 }
 }  // namespace

@@ -9,6 +9,10 @@
 #include <cmath>
 #include <cstdint>
 
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
 #include "bvh_gpu.h"
 
 namespace srd {
@@ -65,7 +69,7 @@ __device__ __forceinline__ void tri_box(const float4* tris, uint32_t slot, float
 __global__ void refit_level_kernel(uint32_t* nodes, const float4* tris, float* node_box, const uint32_t* level_nodes, uint32_t first, uint32_t count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const uint32_t node = level_nodes[first + i];
+    const uint32_t node = level_nodes ? level_nodes[first + i] : first + i;   // null list: the level is the index range itself
     uint32_t* q = nodes + (size_t)node * 16;
     float lo[4][3], hi[4][3];
     bool real[4];
@@ -136,6 +140,236 @@ __global__ void refit_level_kernel(uint32_t* nodes, const float4* tris, float* n
     for (int a = 0; a < 3; a++) { b[a] = lo_n[a]; b[3 + a] = hi_n[a]; }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// OpType::FastBuild on the device (PREFER_FAST_BUILD, acceleration_structure/mod.rs:33-35): a linear BVH.
+//   prims      world-space triangle records + centroids of their padded boxes, scene bounds (wave-reduced atomics)
+//   morton     63-bit Morton code of the centroid (21 bits per axis), radix-sorted with the triangle id (hipCUB)
+//   hierarchy  binary radix tree over the sorted codes (Karras 2012; equal codes are split by index)
+//   fit        bottom-up: box and "binary walk height" of every radix node (second arriver continues upward)
+//   collapse   top-down, one launch per level: radix subtrees of <= 4 triangles become leaves (their triangles are
+//              consecutive in sorted order = leaf order), inner nodes take up to 4 children by repeatedly opening
+//              the child with the largest box while the stack budget allows (same rule as bvh_build.cpp's Collapser)
+//   leaves     triangle / shade / shade_tex records in leaf order, slot_of_gid
+//   refit      the kernel above computes the boxes of the 4-wide nodes and quantises them, deepest level first
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t find_instance(const FlatInstance* inst, uint32_t n_inst, uint32_t gid) {
+    uint32_t lo = 0, hi = n_inst;            // last instance whose tri_offset <= gid
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (inst[mid].tri_offset <= gid) lo = mid; else hi = mid; }
+    return lo;
+}
+__device__ __forceinline__ uint32_t enc_f(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float dec_f(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e); }
+
+__global__ void lbvh_prims_kernel(const SrMeshInfo* meshes, const FlatInstance* instances, uint32_t n_inst, uint32_t n_tris, float4* W, float4* cent,
+                                  uint32_t* bounds_enc) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (gid < n_tris) {
+        const uint32_t ii = find_instance(instances, n_inst, gid);
+        const FlatInstance inst = instances[ii];
+        float v0[3], e1[3], e2[3];
+        world_triangle(meshes, inst, gid - inst.tri_offset, v0, e1, e2);
+        W[(size_t)gid * 3 + 0] = make_float4(v0[0], v0[1], v0[2], e1[0]);
+        W[(size_t)gid * 3 + 1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
+        W[(size_t)gid * 3 + 2] = make_float4(e2[2], __uint_as_float(gid), 0.0f, 0.0f);
+        tri_box(W, gid, lo, hi);
+        cent[gid] = make_float4(0.5f * lo[0] + 0.5f * hi[0], 0.5f * lo[1] + 0.5f * hi[1], 0.5f * lo[2] + 0.5f * hi[2], __uint_as_float(ii));
+    }
+    for (int a = 0; a < 3; a++) {
+        float l = lo[a], h = hi[a];
+        for (int o = 32; o > 0; o >>= 1) { l = fminf(l, __shfl_xor(l, o)); h = fmaxf(h, __shfl_xor(h, o)); }
+        if ((threadIdx.x & 63) == 0) {
+            if (l <= h) { atomicMin(bounds_enc + a, enc_f(l)); atomicMax(bounds_enc + 3 + a, enc_f(h)); }
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned long long spread21(uint32_t v) {   // 21 bits -> every third bit
+    unsigned long long x = v & 0x1FFFFFull;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void lbvh_morton_kernel(const float4* cent, const uint32_t* bounds_enc, uint32_t n_tris, unsigned long long* keys, uint32_t* vals) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_tris) return;
+    const float4 c = cent[gid];
+    const float p[3] = {c.x, c.y, c.z};
+    uint32_t q[3];
+    for (int a = 0; a < 3; a++) {
+        const float lo = dec_f(bounds_enc[a]), hi = dec_f(bounds_enc[3 + a]);
+        const float ext = hi - lo;
+        float t = ext > 0.0f ? (p[a] - lo) / ext : 0.0f;
+        t = fminf(fmaxf(t, 0.0f), 1.0f);                      // NaN -> 0
+        q[a] = min((uint32_t)(t * 2097152.0f), 2097151u);
+    }
+    keys[gid] = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
+    vals[gid] = gid;
+}
+
+// delta(i, j): length of the common prefix of the sorted codes, ties broken by the index (Karras 2012, section 4)
+__device__ __forceinline__ int lbvh_delta(const unsigned long long* keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long a = keys[i], b = keys[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz(i ^ j);
+}
+
+__global__ void lbvh_hierarchy_kernel(const unsigned long long* keys, int n, int2* children, uint32_t* parent_of_inner, uint32_t* parent_of_leaf, uint2* range) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = lbvh_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (lbvh_delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1) if (lbvh_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = lbvh_delta(keys, n, i, j);
+    int s = 0;
+    for (int t = l;;) {
+        t = (t + 1) >> 1;
+        if (lbvh_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break;
+    }
+    const int gamma = i + s * d + min(d, 0);
+    const int first = min(i, j), last = max(i, j);
+    int2 ch;
+    ch.x = first == gamma ? ~gamma : gamma;               // leaf k is encoded ~k
+    ch.y = last == gamma + 1 ? ~(gamma + 1) : gamma + 1;
+    children[i] = ch;
+    range[i] = make_uint2((uint32_t)first, (uint32_t)last);
+    if (ch.x >= 0) parent_of_inner[ch.x] = (uint32_t)i; else parent_of_leaf[~ch.x] = (uint32_t)i;
+    if (ch.y >= 0) parent_of_inner[ch.y] = (uint32_t)i; else parent_of_leaf[~ch.y] = (uint32_t)i;
+    if (i == 0) parent_of_inner[0] = 0xFFFFFFFFu;
+}
+
+// Bottom-up fit: boxes of the radix nodes and the stack height of a purely binary walk below each (0 for subtrees that
+// will become leaves), second arriver at a node continues (the first one's writes are visible after the fence).
+__global__ void lbvh_fit_kernel(const float4* W, const uint32_t* sorted_gid, int n, const int2* children, const uint32_t* parent_of_inner,
+                                const uint32_t* parent_of_leaf, const uint2* range, float* bin_box, uint32_t* bin_height, uint32_t* flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t node = parent_of_leaf[i];
+    while (node != 0xFFFFFFFFu) {
+        __threadfence();
+        if (atomicAdd(flags + node, 1u) == 0u) return;
+        __threadfence();
+        const int2 ch = children[node];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t h = 0;
+        const int cc[2] = {ch.x, ch.y};
+        for (int c = 0; c < 2; c++) {
+            if (cc[c] < 0) tri_box(W, sorted_gid[~cc[c]], lo, hi);
+            else {
+                const volatile float* b = bin_box + (size_t)cc[c] * 6;
+                for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], b[a]); hi[a] = fmaxf(hi[a], b[3 + a]); }
+                h = max(h, ((const volatile uint32_t*)bin_height)[cc[c]]);
+            }
+        }
+        const uint2 r = range[node];
+        float* b = bin_box + (size_t)node * 6;
+        for (int a = 0; a < 3; a++) { b[a] = lo[a]; b[3 + a] = hi[a]; }
+        bin_height[node] = (r.y - r.x + 1u <= 4u) ? 0u : h + 1u;
+        node = parent_of_inner[node];
+    }
+}
+
+struct LbvhKid { int bin; uint32_t first, count; float area; uint32_t need; };   // bin >= 0: inner (radix node), else leaf range
+
+__device__ __forceinline__ LbvhKid lbvh_kid(int ref, const uint2* range, const float* bin_box, const uint32_t* bin_height) {
+    LbvhKid k;
+    if (ref < 0) { k.bin = -1; k.first = (uint32_t)~ref; k.count = 1; k.area = 0.0f; k.need = 0; return k; }
+    const uint2 r = range[ref];
+    const uint32_t size = r.y - r.x + 1u;
+    if (size <= 4u) { k.bin = -1; k.first = r.x; k.count = size; k.area = 0.0f; k.need = 0; return k; }
+    const float* b = bin_box + (size_t)ref * 6;
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    k.bin = ref; k.first = r.x; k.count = size; k.area = dx * dy + dy * dz + dz * dx; k.need = bin_height[ref];
+    return k;
+}
+
+// One thread per 4-wide node of the current level. counters: [0] = nodes allocated, [1] = max stack, [2] = overflow flag.
+__global__ void lbvh_collapse_kernel(uint32_t* nodes, uint32_t level_first, uint32_t level_count, uint32_t node_cap, int* bin_of_node, uint32_t* budget_of_node,
+                                     uint32_t* prefix_of_node, const int2* children, const uint2* range, const float* bin_box, const uint32_t* bin_height,
+                                     uint32_t* counters) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= level_count) return;
+    const uint32_t self = level_first + t;
+    const int bin = bin_of_node[self];
+    const uint32_t budget = budget_of_node[self];
+    LbvhKid kids[4];
+    int nk = 0;
+    const int2 ch = children[bin];
+    kids[nk++] = lbvh_kid(ch.x, range, bin_box, bin_height);
+    kids[nk++] = lbvh_kid(ch.y, range, bin_box, bin_height);
+    while (nk < 4) {
+        int best = -1; float best_area = -1.0f;
+        for (int i = 0; i < nk; i++) if (kids[i].bin >= 0 && kids[i].area > best_area) { best_area = kids[i].area; best = i; }
+        if (best < 0) break;
+        const int2 cb = children[kids[best].bin];
+        const LbvhKid ka = lbvh_kid(cb.x, range, bin_box, bin_height), kb = lbvh_kid(cb.y, range, bin_box, bin_height);
+        bool fits = ka.need + (uint32_t)nk <= budget && kb.need + (uint32_t)nk <= budget;   // with nk+1 children every subtree gets budget - nk entries
+        for (int i = 0; i < nk && fits; i++) if (i != best && kids[i].need + (uint32_t)nk > budget) fits = false;
+        if (!fits) break;
+        kids[best] = ka;
+        kids[nk++] = kb;
+    }
+    uint32_t* q = nodes + (size_t)self * 16;
+    for (int k = 0; k < 12; k++) q[k] = 0u;
+    const uint32_t mine = prefix_of_node[self] + (uint32_t)(nk - 1);
+    atomicMax(counters + 1, mine);
+    for (int i = 0; i < 4; i++) {
+        uint32_t ref = 0xFFFFFFFFu;                              // leaf_ref(0, 0): unused child
+        if (i < nk) {
+            if (kids[i].bin >= 0) {
+                const uint32_t idx = atomicAdd(counters + 0, 1u);
+                if (idx < node_cap) {
+                    bin_of_node[idx] = kids[i].bin;
+                    budget_of_node[idx] = budget - (uint32_t)(nk - 1);
+                    prefix_of_node[idx] = mine;
+                    ref = idx;
+                } else { atomicExch(counters + 2, 1u); }
+            } else ref = ~((kids[i].first << 3) | kids[i].count);
+        }
+        q[12 + i] = ref;
+    }
+}
+
+// Leaf-order records: the sorted order is the leaf order.
+__global__ void lbvh_leaves_kernel(const float4* W, const float4* cent, const uint32_t* sorted_gid, uint32_t n_tris, const SrMeshInfo* meshes,
+                                   const FlatInstance* instances, float4* tris, float4* shade, float4* shade_tex, uint32_t* slot_of_gid) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_tris) return;
+    const uint32_t gid = sorted_gid[slot];
+    for (int k = 0; k < 3; k++) tris[(size_t)slot * 3 + k] = W[(size_t)gid * 3 + k];
+    slot_of_gid[gid] = slot;
+    const uint32_t ii = __float_as_uint(cent[gid].w);
+    const FlatInstance inst = instances[ii];
+    const SrMeshInfo mi = meshes[inst.mesh_slot];
+    const uint32_t* idx = (const uint32_t*)(uintptr_t)mi.indices;
+    const SrVertex* vtx = (const SrVertex*)(uintptr_t)mi.vertices;
+    const uint32_t prim = gid - inst.tri_offset;
+    const SrVertex* v[3] = {vtx + idx[3 * prim], vtx + idx[3 * prim + 1], vtx + idx[3 * prim + 2]};
+    shade[(size_t)slot * 3 + 0] = make_float4(v[0]->normal[0], v[0]->normal[1], v[0]->normal[2], v[1]->normal[0]);
+    shade[(size_t)slot * 3 + 1] = make_float4(v[1]->normal[1], v[1]->normal[2], v[2]->normal[0], v[2]->normal[1]);
+    shade[(size_t)slot * 3 + 2] = make_float4(v[2]->normal[2], __uint_as_float(ii), __uint_as_float(inst.mesh_slot), 0.0f);
+    if (shade_tex) {
+        float4* q = shade_tex + (size_t)slot * 6;
+        q[0] = make_float4(v[0]->base_color_tex_coord[0], v[0]->base_color_tex_coord[1], v[1]->base_color_tex_coord[0], v[1]->base_color_tex_coord[1]);
+        q[1] = make_float4(v[2]->base_color_tex_coord[0], v[2]->base_color_tex_coord[1], v[0]->normal_tex_coord[0], v[0]->normal_tex_coord[1]);
+        q[2] = make_float4(v[1]->normal_tex_coord[0], v[1]->normal_tex_coord[1], v[2]->normal_tex_coord[0], v[2]->normal_tex_coord[1]);
+        q[3] = make_float4(v[0]->tangent[0], v[0]->tangent[1], v[0]->tangent[2], v[0]->tangent[3] >= 0.0f ? 1.0f : -1.0f);
+        q[4] = make_float4(v[1]->tangent[0], v[1]->tangent[1], v[1]->tangent[2], v[2]->tangent[0]);
+        q[5] = make_float4(v[2]->tangent[1], v[2]->tangent[2], 0.0f, 0.0f);
+    }
+}
+
 }  // namespace srd
 
 using namespace srd;
@@ -154,4 +388,89 @@ int srk_launch_refit(uint32_t* nodes, const float4* tris, float* node_box, const
         refit_level_kernel<<<dim3((count + 63) / 64), dim3(64), 0, stream>>>(nodes, tris, node_box, level_nodes, first, count);
     }
     return (int)hipGetLastError();
+}
+
+// Device LBVH build. All outputs are device buffers owned by the caller; `scratch` is reused across builds. Returns 0, a
+// hipError_t (> 0), or -1 when the tree does not fit the limits (caller falls back to the host builder).
+int srk_lbvh_build(const LbvhArgs& a, LbvhResult* out, hipStream_t stream) {
+    const uint32_t n = a.n_tris;
+    const int B = 256;
+    const dim3 gt((n + B - 1) / B), bt(B);
+    // carve the scratch slab
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void* p = (char*)a.scratch + off; off += (bytes + 255) & ~(size_t)255; return p; };
+    float4* W = (float4*)take((size_t)n * 48);
+    float4* cent = (float4*)take((size_t)n * 16);
+    unsigned long long* keys_a = (unsigned long long*)take((size_t)n * 8);
+    unsigned long long* keys_b = (unsigned long long*)take((size_t)n * 8);
+    uint32_t* vals_a = (uint32_t*)take((size_t)n * 4);
+    uint32_t* vals_b = (uint32_t*)take((size_t)n * 4);
+    int2* children = (int2*)take((size_t)n * 8);
+    uint2* range = (uint2*)take((size_t)n * 8);
+    uint32_t* parent_inner = (uint32_t*)take((size_t)n * 4);
+    uint32_t* parent_leaf = (uint32_t*)take((size_t)n * 4);
+    float* bin_box = (float*)take((size_t)n * 24);
+    uint32_t* bin_height = (uint32_t*)take((size_t)n * 4);
+    uint32_t* flags = (uint32_t*)take((size_t)n * 4);
+    int* bin_of_node = (int*)take((size_t)a.node_cap * 4);
+    uint32_t* budget_of_node = (uint32_t*)take((size_t)a.node_cap * 4);
+    uint32_t* prefix_of_node = (uint32_t*)take((size_t)a.node_cap * 4);
+    uint32_t* small = (uint32_t*)take(256);          // [0..5] bounds, [8..10] counters
+    size_t cub_bytes = 0;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, stream);
+    if (e != hipSuccess) return (int)e;
+    void* cub_tmp = take(cub_bytes);
+    if (off > a.scratch_bytes) return (int)hipErrorOutOfMemory;
+
+    const uint32_t init[16] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if ((e = hipMemcpyAsync(small, init, sizeof(init), hipMemcpyHostToDevice, stream)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(flags, 0, (size_t)n * 4, stream)) != hipSuccess) return (int)e;
+    lbvh_prims_kernel<<<gt, bt, 0, stream>>>(a.meshes, a.instances, a.n_instances, n, W, cent, small);
+    lbvh_morton_kernel<<<gt, bt, 0, stream>>>(cent, small, n, keys_a, vals_a);
+    if ((e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, stream)) != hipSuccess) return (int)e;
+    lbvh_hierarchy_kernel<<<gt, bt, 0, stream>>>(keys_b, (int)n, children, parent_inner, parent_leaf, range);
+    lbvh_fit_kernel<<<gt, bt, 0, stream>>>(W, vals_b, (int)n, children, parent_inner, parent_leaf, range, bin_box, bin_height, flags);
+    // root of the 4-wide tree = radix node 0; its budget is the binary height, at least the regular stack size
+    uint32_t root_height = 0;
+    if ((e = hipMemcpyAsync(&root_height, bin_height, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
+    if (root_height > a.stack_cap) return -1;
+    const uint32_t budget = root_height > a.stack_floor ? root_height : a.stack_floor;
+    const int root_init[1] = {0};
+    const uint32_t zero = 0;
+    (void)hipMemcpyAsync(bin_of_node, root_init, 4, hipMemcpyHostToDevice, stream);
+    (void)hipMemcpyAsync(budget_of_node, &budget, 4, hipMemcpyHostToDevice, stream);
+    (void)hipMemcpyAsync(prefix_of_node, &zero, 4, hipMemcpyHostToDevice, stream);
+    out->level_ranges.clear();
+    uint32_t level_first = 0, level_count = 1;
+    uint32_t* counters = small + 8;
+    while (level_count) {
+        out->level_ranges.emplace_back(level_first, level_count);
+        lbvh_collapse_kernel<<<dim3((level_count + 63) / 64), dim3(64), 0, stream>>>((uint32_t*)a.nodes, level_first, level_count, a.node_cap, bin_of_node,
+                                                                                       budget_of_node, prefix_of_node, children, range, bin_box, bin_height, counters);
+        uint32_t c[3];
+        if ((e = hipMemcpyAsync(c, counters, 12, hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
+        if (c[2] || c[0] > a.node_cap) return -1;
+        level_first += level_count;
+        level_count = c[0] - level_first;
+        out->n_nodes = c[0];
+        out->max_stack = c[1];
+        if (out->level_ranges.size() > 128) return -1;
+    }
+    out->max_depth = (uint32_t)out->level_ranges.size();
+    lbvh_leaves_kernel<<<gt, bt, 0, stream>>>(W, cent, vals_b, n, a.meshes, a.instances, a.tris, a.shade, a.shade_tex, a.slot_of_gid);
+    for (size_t l = out->level_ranges.size(); l-- > 0;)
+        refit_level_kernel<<<dim3((out->level_ranges[l].second + 63) / 64), dim3(64), 0, stream>>>((uint32_t*)a.nodes, a.tris, a.node_box, nullptr,
+                                                                                                     out->level_ranges[l].first, out->level_ranges[l].second);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
+    return 0;
+}
+
+size_t srk_lbvh_scratch_bytes(uint32_t n_tris, uint32_t node_cap) {
+    size_t cub_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr,
+                                             (uint32_t*)nullptr, (int)n_tris, 0, 63, nullptr);
+    return (size_t)n_tris * (48 + 16 + 16 + 8 + 8 + 8 + 4 + 4 + 24 + 4 + 4) + (size_t)node_cap * 12 + cub_bytes + 64 * 256;
 }

@@ -189,6 +189,9 @@ class Scene:
             xf = np.zeros((1, 12), dtype=np.float32)
         check(lib().sr_scene_set_instances(self._h, _p(keys), _p(counts), C.c_uint32(len(keys)), _p(np.ascontiguousarray(xf))))
 
+    def force_next_op(self, op):
+        check(lib().sr_scene_force_next_op(self._h, C.c_uint32(op)))
+
     def end_frame(self):
         check(lib().sr_scene_end_frame(self._h))
 

@@ -596,6 +596,66 @@ def test_dynamic_instances_update_in_place_and_rebuild_cycle(rt, oracle, blue_no
     assert quiet == [abi.OP_NONE] * 15 + [S] + [abi.OP_NONE] and gsc.as_state()[0].changing == 0
 
 
+@pytest.mark.parametrize("scene_fn,box", [
+    (scenes.torus_knot, ((-4, 0, -4), (4, 5, 4))),
+    (lambda: scenes.heightfield(n=300), ((-15, 0, -15), (15, 9, 15))),
+    (lambda: scenes.atrium(columns_per_side=6, col_segments=24, col_rings=6, floor_div=16, tex=32, n_lamps=8), ((-8, 0.1, -17), (8, 6.5, 17))),
+])
+def test_device_lbvh_fast_build(rt, oracle, blue_noise, scene_fn, box):
+    """OpType::FastBuild = linear BVH built on the device: a valid conservative tree, the same query results as the
+    oracle (results do not depend on the tree), and it can be updated in place afterwards."""
+    from test_host_abi import _check_bvh
+    desc = scene_fn()
+    osc = oracle.OracleScene().load(desc)
+    gsc = rt.Scene(0).load(desc)
+    sah = gsc.bvh_stats()
+    gsc.force_next_op(abi.OP_FAST_BUILD)
+    gsc.set_instances(desc.instances)
+    st = gsc.bvh_stats()
+    assert gsc.as_state()[1] == abi.OP_FAST_BUILD and st.n_triangles == sah.n_triangles and st.sah_cost == 0.0   # built on the device
+    print("%s: %d tris, host SAH %.1f ms (%d nodes, stack %d) | device LBVH %.2f ms (%d nodes, depth %d, stack %d)" % (
+        desc.name, st.n_triangles, sah.build_ms, sah.n_nodes, sah.max_stack, st.build_ms, st.n_nodes, st.max_depth, st.max_stack))
+    nodes, tris = gsc.read_bvh()
+    _check_bvh(nodes, tris, st.max_depth, st.max_stack, stack_limit=48)
+    rays = np.concatenate([camera_rays(oracle, desc, 160, 90), random_rays(20000, 5, box=box)])
+    rays_t = rt.rays_to_device(rays)
+    hits_t = gsc.trace_closest(rays_t, len(rays))
+    hits = rt.hits_from_device(hits_t)
+    assert_bits_equal(osc.trace_closest(rays), hits, "SrHit (LBVH)")
+    assert np.array_equal(osc.trace_any(rays), gsc.trace_any(rays_t, len(rays)).cpu().numpy().view(np.uint32))
+    pl = gsc.shade_closest_hit(hits_t, len(rays)).cpu().numpy().view(np.uint32).reshape(-1).view(abi.RAY_PAYLOAD)
+    assert_bits_equal(osc.shade_closest_hit(hits), pl, "RayPayload (device-built shade records)")
+    W, H = 160, 96
+    of, gf = oracle.HostFrame(W, H, blue_noise), rt.DeviceFrame(W, H, blue_noise)
+    om = oracle.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H)
+    gm = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H)
+    osc.trace_ris(of, om, 0); osc.trace_final(of, om, 0)
+    gsc.trace_ris(gf, gm, 0); gsc.trace_final(gf, gm, 0)
+    assert_bits_equal(of.raw_color, gf.host()["raw_color"], "raw_color (LBVH)")
+    # an in-place update of the device-built tree
+    inst = [(k, [np.asarray(x, dtype=np.float32) + np.float32(0.05) * np.eye(3, 4, 3, dtype=np.float32).reshape(12) for x in xs]) for k, xs in desc.instances]
+    gsc.set_instances(inst); osc.set_instances(inst)
+    assert gsc.as_state()[1] == abi.OP_UPDATE
+    assert_bits_equal(osc.trace_closest(rays), rt.hits_from_device(gsc.trace_closest(rays_t, len(rays))), "SrHit (LBVH + update)")
+    nodes, tris = gsc.read_bvh()
+    _check_bvh(nodes, tris, st.max_depth, st.max_stack, stack_limit=48)
+
+
+def test_device_lbvh_1m_triangles(rt, oracle):
+    desc = scenes.heightfield(708)
+    gsc = rt.Scene(0).load(desc)
+    sah = gsc.bvh_stats()
+    for rep in range(2):           # second build: scratch already allocated, kernels loaded
+        gsc.force_next_op(abi.OP_FAST_BUILD)
+        gsc.set_instances(desc.instances)
+    st = gsc.bvh_stats()
+    print("1M tris: host SAH %.1f ms (%d nodes, stack %d) | device LBVH %.2f ms (%d nodes, depth %d, stack %d, on device: %s)" % (
+        sah.build_ms, sah.n_nodes, sah.max_stack, st.build_ms, st.n_nodes, st.max_depth, st.max_stack, st.sah_cost == 0.0))
+    osc = oracle.OracleScene().load(desc)
+    rays = camera_rays(oracle, desc, 320, 180)
+    assert_bits_equal(osc.trace_closest(rays), rt.hits_from_device(gsc.trace_closest(rt.rays_to_device(rays), len(rays))), "SrHit 1M (LBVH)")
+
+
 def test_update_in_place_large_scene_timing(rt, oracle):
     """1M-triangle scene + a moving light rig: an in-place update must be far cheaper than the host rebuild and give
     the same hits as the oracle."""

@@ -90,7 +90,7 @@ def _world_tris(desc):
     return np.concatenate(out).astype(np.float32)
 
 
-def _check_bvh(nodes, tris, max_depth, max_stack):
+def _check_bvh(nodes, tris, max_depth, max_stack, stack_limit=32):
     """Walks the 64-byte quantised 4-wide nodes exactly as the kernel decodes them (traverse.h)."""
     n = len(tris)
     seen = np.zeros(n, dtype=int)
@@ -105,7 +105,7 @@ def _check_bvh(nodes, tris, max_depth, max_stack):
         for c in range(4):
             lo, hi = lo4[c], hi4[c]
             if ch[c] >= 0:
-                assert ch[c] > node  # depth-first order: children follow their parent
+                assert ch[c] > node  # children always follow their parent (depth-first on the host, breadth-first on the device)
                 l2, h2, sb = rec(int(ch[c]), depth + 1)
                 stack_below = max(stack_below, sb)
             else:
@@ -136,7 +136,7 @@ def _check_bvh(nodes, tris, max_depth, max_stack):
     assert (seen == 1).all()
     assert sorted(tris[:, 9].view(np.uint32)) == list(range(n))
     assert depth_seen[0] == max_depth
-    assert need == max_stack <= 32   # kStackMax (traverse.h): the builder narrows nodes where the budget is tight
+    assert need == max_stack <= stack_limit   # kStackMax (traverse.h): the builder narrows nodes where the budget is tight
     return slack[0]
 
 
