@@ -6,7 +6,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsunray_hip.so")
+LIB_PATH = os.environ.get("SUNRAY_HIP_LIB") or os.path.join(_HERE, "libsunray_hip.so")   # override: kernel-tuning variants only
 _lib = None
 
 # every symbol include/sunray_hip.h declares

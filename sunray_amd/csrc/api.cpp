@@ -438,7 +438,7 @@ int full_build(SrScene* s);
 // OpType::FastBuild: linear BVH built on the device (bvh_gpu.hip). Falls back to the host builder for small scenes
 // and for trees that would need a deeper traversal stack than one workgroup's LDS share.
 constexpr uint32_t kDeviceBuildMinTris = 4096;
-constexpr uint32_t kDeviceStackCap = 48;
+constexpr uint32_t kDeviceStackCap = 47;
 int fast_build(SrScene* s) {
     const uint32_t n = s->fid.n_triangles;
     if (n < kDeviceBuildMinTris) return full_build(s);
@@ -491,7 +491,7 @@ int fast_build(SrScene* s) {
     s->stats.tri_bytes = (uint64_t)n * 48;
     s->stats.max_depth = r.max_depth;
     s->stats.max_stack = r.max_stack;
-    s->stack_entries = (int)((std::max(r.max_stack, 4u) + 3u) & ~3u);
+    s->stack_entries = (int)((std::max(r.max_stack, 3u) + 1u + 3u) & ~3u);
     s->stats.sah_cost = 0.0f;
     s->stats.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     s->built = true;
@@ -651,7 +651,7 @@ int full_build(SrScene* s) {
     s->stats.tri_bytes = (uint64_t)s->fid.n_triangles * 48;
     s->stats.max_depth = bvh.max_depth;
     s->stats.max_stack = bvh.max_stack;
-    s->stack_entries = (int)((std::max(bvh.max_stack, 4u) + 3u) & ~3u);
+    s->stack_entries = (int)((std::max(bvh.max_stack, 3u) + 1u + 3u) & ~3u);   // + the spare level of the branch-free push
     s->stats.sah_cost = bvh.sah_cost;
     s->stats.build_ms = bvh.build_ms;
     s->built = true;
@@ -770,9 +770,6 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
     a.frame_count = p->frame_count;
     a.width = p->width; a.height = p->height;
     a.y0 = y0; a.y1 = y1;
-    a.tiles_x = (p->width + 15) / 16;
-    a.tiles_y = (y1 - y0 + 15) / 16;
-    a.tiles_per_xcd = ((a.tiles_x + 7) / 8) * a.tiles_y;   // widest column band x rows (kernels.hip thread_pixel)
     a.cfg = p->config;
     hipStream_t st = (hipStream_t)stream;
     ScopedTiming tm(s, which == 0 ? kRis : kFinal, st);

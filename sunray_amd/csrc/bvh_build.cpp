@@ -228,6 +228,11 @@ inline float area_of(const Child4& c) {
     if (!(dx >= 0.0f)) return -1.0f;
     return dx * dy + dy * dz + dz * dx;
 }
+// Guard band around every quantised plane, in grid cells: the traversal evaluates plane distances as fma(q, 2^e*inv,
+// (origin-o)*inv) (traverse.h), whose rounding must stay inside it. The lower plane of a child that touches the node's
+// own minimum stays at q = 0: the node origin is nudged down instead.
+constexpr double kGuardCells = 1.0 / 32.0;
+
 struct Collapser {
     const std::vector<float>& n2;
     std::vector<uint32_t>& out;   // 16 dwords per node
@@ -283,16 +288,16 @@ struct Collapser {
         float origin[3] = {0.0f, 0.0f, 0.0f};
         if (n_real > 0) {
             for (int a = 0; a < 3; a++) {
-                origin[a] = lo_n[a];
-                const float ext = hi_n[a] - lo_n[a];
+                origin[a] = std::nextafter(lo_n[a] - (hi_n[a] - lo_n[a]) * (1.0f / 2048.0f), -INFINITY);   // ~1/8 cell below the minimum
+                const float ext = hi_n[a] - origin[a];
                 int e = -126;
-                if (ext > 0.0f) { int fe; (void)std::frexp(ext / 255.0f, &fe); e = std::max(fe, -126); }   // 2^fe >= ext/255
+                if (ext > 0.0f && ext / 255.0f > 0.0f) { int fe; (void)std::frexp(ext / 255.0f, &fe); e = std::max(fe, -126); }   // 2^fe >= ext/255
                 for (;;) {   // grow the grid until every child's upper plane fits in a byte
                     const float scale = std::ldexp(1.0f, e);
                     bool ok = true;
                     for (int i = 0; i < nk && ok; i++) {
                         if (!real[i]) continue;
-                        int qh = (int)std::ceil(((double)kids[i].hi[a] - (double)origin[a]) / (double)scale);
+                        int qh = (int)std::ceil(((double)kids[i].hi[a] - (double)origin[a]) / (double)scale + kGuardCells);
                         qh = std::max(qh, 0);
                         while (qh <= 255 && fmaf((float)qh, scale, origin[a]) < kids[i].hi[a]) qh++;
                         if (qh > 255) ok = false;
@@ -305,10 +310,10 @@ struct Collapser {
                 for (int i = 0; i < 4; i++) {
                     uint32_t ql = 255u, qh = 0u;   // inverted box for unused children
                     if (i < nk && real[i]) {
-                        int l = (int)std::floor(((double)kids[i].lo[a] - (double)origin[a]) / (double)scale);
+                        int l = (int)std::floor(((double)kids[i].lo[a] - (double)origin[a]) / (double)scale - kGuardCells);
                         l = std::min(std::max(l, 0), 255);
                         while (l > 0 && fmaf((float)l, scale, origin[a]) > kids[i].lo[a]) l--;
-                        int h = (int)std::ceil(((double)kids[i].hi[a] - (double)origin[a]) / (double)scale);
+                        int h = (int)std::ceil(((double)kids[i].hi[a] - (double)origin[a]) / (double)scale + kGuardCells);
                         h = std::max(h, 0);
                         while (fmaf((float)h, scale, origin[a]) < kids[i].hi[a]) h++;
                         ql = (uint32_t)l; qh = (uint32_t)h;

@@ -66,6 +66,8 @@ __device__ __forceinline__ void tri_box(const float4* tris, uint32_t slot, float
 // from the already refitted child nodes (node_box), then the same quantisation the host collapser applies
 // (bvh_build.cpp Collapser::emit): origin = node min, per-axis power-of-two grid, planes rounded outward and
 // verified with the decode expression fmaf(q, 2^e, origin).
+constexpr double kGuardCells = 1.0 / 32.0;   // guard band around every quantised plane (see bvh_build.cpp, traverse.h)
+
 __global__ void refit_level_kernel(uint32_t* nodes, const float4* tris, float* node_box, const uint32_t* level_nodes, uint32_t first, uint32_t count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -96,17 +98,17 @@ __global__ void refit_level_kernel(uint32_t* nodes, const float4* tris, float* n
     float origin[3] = {0.0f, 0.0f, 0.0f};
     if (n_real > 0) {
         for (int a = 0; a < 3; a++) {
-            origin[a] = lo_n[a];
-            const float ext = hi_n[a] - lo_n[a];
+            origin[a] = nextafterf(lo_n[a] - (hi_n[a] - lo_n[a]) * (1.0f / 2048.0f), -INFINITY);   // ~1/8 cell below the minimum
+            const float ext = hi_n[a] - origin[a];
             int e = -126;
-            if (ext > 0.0f && ext < INFINITY) { int fe; (void)frexpf(ext / 255.0f, &fe); e = max(fe, -126); }
+            if (ext > 0.0f && ext < INFINITY && ext / 255.0f > 0.0f) { int fe; (void)frexpf(ext / 255.0f, &fe); e = max(fe, -126); }
             if (!(ext < INFINITY)) e = 127;
             for (; e < 127; e++) {   // grow the grid until every child's upper plane fits in a byte
                 const float scale = ldexpf(1.0f, e);
                 bool ok = true;
                 for (int c = 0; c < 4 && ok; c++) {
                     if (!real[c]) continue;
-                    int qh = (int)ceil(((double)hi[c][a] - (double)origin[a]) / (double)scale);
+                    int qh = (int)ceil(((double)hi[c][a] - (double)origin[a]) / (double)scale + kGuardCells);
                     qh = max(qh, 0);
                     while (qh <= 255 && fmaf((float)qh, scale, origin[a]) < hi[c][a]) qh++;
                     if (qh > 255) ok = false;
@@ -118,10 +120,10 @@ __global__ void refit_level_kernel(uint32_t* nodes, const float4* tris, float* n
             for (int c = 0; c < 4; c++) {
                 uint32_t ql = 255u, qh = 0u;   // inverted box for unused children
                 if (real[c]) {
-                    int l = (int)floor(((double)lo[c][a] - (double)origin[a]) / (double)scale);
+                    int l = (int)floor(((double)lo[c][a] - (double)origin[a]) / (double)scale - kGuardCells);
                     l = min(max(l, 0), 255);
                     while (l > 0 && fmaf((float)l, scale, origin[a]) > lo[c][a]) l--;
-                    int h = (int)ceil(((double)hi[c][a] - (double)origin[a]) / (double)scale);
+                    int h = (int)ceil(((double)hi[c][a] - (double)origin[a]) / (double)scale + kGuardCells);
                     h = min(max(h, 0), 255);
                     while (h < 255 && fmaf((float)h, scale, origin[a]) < hi[c][a]) h++;
                     ql = (uint32_t)l; qh = (uint32_t)h;

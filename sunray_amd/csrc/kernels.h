@@ -23,7 +23,7 @@ struct PassArgs {
     uint32_t frame_count;
     uint32_t width, height;
     uint32_t y0, y1;              // rows [y0, y1) of the image are traced by this launch
-    uint32_t tiles_x, tiles_y;    // 16x16 tiles covering width x (y1 - y0)
+    uint32_t tiles_x, tiles_y;    // pixel tiles covering width x (y1 - y0); filled in by srk_launch_pass
     uint32_t tiles_per_xcd;       // ceil(tiles_x / 8) * tiles_y: blocks per XCD (column bands)
     SrTraceConfig cfg;
 };

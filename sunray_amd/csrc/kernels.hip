@@ -14,7 +14,18 @@
 
 namespace srd {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 256;        // ray-queue and shade kernels
+#ifndef SR_PASS_BLOCK
+#define SR_PASS_BLOCK 64
+#endif
+constexpr int kPassBlock = SR_PASS_BLOCK;                 // the two pass megakernels: one wave = one 8x8 pixel tile
+constexpr int kPassTile = kPassBlock == 256 ? 16 : 8;     // (256 threads: 16x16 tile of four 8x8 wave tiles)
+#ifndef SR_RIS_WAVES
+#define SR_RIS_WAVES 4
+#endif
+#ifndef SR_FINAL_WAVES
+#define SR_FINAL_WAVES 4
+#endif                                                    // __launch_bounds__ second argument on HIP: waves per SIMD (4 -> VGPR budget 128)
 
 // Wave-wide sum, then one atomic per wave (rays are counted, not estimated: SURVEY.md §8d).
 SRD void flush_counter(unsigned long long* dst, uint32_t v) {
@@ -104,7 +115,7 @@ struct PixelCtx {
 template <int V>
 SRD Payload trace_closest_shaded(PixelCtx& cx, f3 o, f3 d, float tmin, float tmax) {
     TravHit h;
-    traverse<false, (V & 1) != 0>(cx.a.sc, o, d, tmin, tmax, h, cx.stack, kBlock, cx.st);
+    traverse<false, (V & 1) != 0>(cx.a.sc, o, d, tmin, tmax, h, cx.stack, kPassBlock, cx.st);
     cx.n_closest++;
     return shade_hit<(V & 2) != 0>(cx.a.sc, h);
 }
@@ -115,7 +126,7 @@ SRD float trace_shadow(PixelCtx& cx, f3 o, f3 d, float dist) {
     if (dist > 0.002f) {
         TravHit h;
         cx.n_any++;
-        return traverse<true, (V & 1) != 0>(cx.a.sc, o, d, 0.001f, dist - 0.001f, h, cx.stack, kBlock, cx.st) ? 1.0f : -1.0f;
+        return traverse<true, (V & 1) != 0>(cx.a.sc, o, d, 0.001f, dist - 0.001f, h, cx.stack, kPassBlock, cx.st) ? 1.0f : -1.0f;
     }
     return -1.0f;
 }
@@ -188,14 +199,14 @@ SRD bool thread_pixel(const PassArgs& a, uint32_t& px, uint32_t& py) {
     if (bw == 0u || k >= bw * a.tiles_y) return false;
     const uint32_t tx = bx0 + k % bw, ty = k / bw;
     const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
-    px = tx * 16u + (w & 1u) * 8u + (l & 7u);
-    py = a.y0 + ty * 16u + (w >> 1) * 8u + (l >> 3);
+    px = tx * (uint32_t)kPassTile + (w & 1u) * 8u + (l & 7u);
+    py = a.y0 + ty * (uint32_t)kPassTile + (w >> 1) * 8u + (l >> 3);
     return px < a.width && py < a.y1;
 }
 
 template <int V>
-__global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
-    extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kBlock], sized at launch
+__global__ __launch_bounds__(kPassBlock, SR_RIS_WAVES) void ris_kernel(const PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kPassBlock], sized at launch
     PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
     const DevScene& sc = a.sc;
     uint32_t px = 0, py = 0;
@@ -434,8 +445,8 @@ __global__ __launch_bounds__(kBlock) void ris_kernel(const PassArgs a) {
 }
 
 template <int V>
-__global__ __launch_bounds__(kBlock) void final_kernel(const PassArgs a) {
-    extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kBlock], sized at launch
+__global__ __launch_bounds__(kPassBlock, SR_FINAL_WAVES) void final_kernel(const PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kPassBlock], sized at launch
     PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
     const DevScene& sc = a.sc;
     uint32_t px = 0, py = 0;
@@ -731,11 +742,15 @@ int srk_launch_shade(const DevScene& sc, const SrHit* hits, uint32_t n, SrRayPay
 
 // Kernel variant V: bit 0 = traversal statistics (instrumented build), bit 1 = the scene has textured materials
 // (closest_hit's texture half compiled in). Untextured scenes run the variant without it.
-int srk_launch_pass(const PassArgs& args, int which, int stats, int textured, int stack_entries, hipStream_t stream) {
+int srk_launch_pass(const PassArgs& args_in, int which, int stats, int textured, int stack_entries, hipStream_t stream) {
+    PassArgs args = args_in;
+    args.tiles_x = (args.width + kPassTile - 1) / kPassTile;
+    args.tiles_y = (args.y1 - args.y0 + kPassTile - 1) / kPassTile;
+    args.tiles_per_xcd = ((args.tiles_x + 7) / 8) * args.tiles_y;   // widest column band x rows (thread_pixel)
     const uint32_t n_tiles = args.tiles_x * args.tiles_y;
     if (n_tiles == 0) return 0;
-    dim3 grid(args.tiles_per_xcd * 8), block(kBlock);
-    const size_t lds = (size_t)stack_entries * kBlock * sizeof(int);
+    dim3 grid(args.tiles_per_xcd * 8), block(kPassBlock);
+    const size_t lds = (size_t)stack_entries * kPassBlock * sizeof(int);
     const int v = (stats ? 1 : 0) | (textured ? 2 : 0);
     if (which == 0) {
         switch (v) {

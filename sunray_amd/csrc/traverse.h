@@ -23,9 +23,10 @@
 
 namespace srd {
 
-constexpr int kStackMax = 32;         // LDS stack entries per lane the builder shapes the tree for (= kMaxBinaryDepth);
-                                      // launches size the dynamic LDS stack to what the scene's tree actually needs
-constexpr int kMaxBinaryDepth = 32;  // depth bound of the binary tree the 4-wide tree is collapsed from
+constexpr int kStackMax = 31;         // stack entries per lane the builders shape a tree for (= kMaxBinaryDepth); with the
+                                      // spare level of the branch-free push that is 32 LDS levels = 32 KB per workgroup.
+                                      // Launches size the dynamic LDS stack to what the scene's tree actually needs.
+constexpr int kMaxBinaryDepth = 31;  // depth bound of the binary tree the 4-wide tree is collapsed from
 constexpr int kSentinel = 0x7fffffff;
 
 struct DevInstance {   // 96 B: (float3x3)WorldToObject3x4 in w2o[0..8], (float3x3)ObjectToWorld3x4 in o2w[0..8], row-major
@@ -113,40 +114,43 @@ SRD bool intersect_tri(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax, 
     return (u >= -kBaryEps) && (v >= -kBaryEps) && (u + v <= 1.0f + kBaryEps) && (t > tmin) && (t < tmax);
 }
 
-// Conservative slab tests: a box is only rejected if no triangle hit with t in
-// (t_lo, t_hi] can lie inside it. Planes are taken in the ray's own order, so a zero direction
-// component yields -inf/+inf inside the slab and NaN exactly on a face; v_max/v_min (IEEE
-// maxNum/minNum) drop the NaN, i.e. slabs are closed. The far side is inflated (Ize 2013).
+// Conservative slab tests: a box is only rejected if no triangle hit with t in (t_lo, t_hi] can lie
+// inside it. Planes are taken in the ray's own order. The plane distance t = (origin + q*2^e - o) / d is evaluated as
+// fma(q, A, B) with the per-node, per-axis constants A = 2^e * inv (exact: a power of two times inv) and
+// B = (origin - o) * inv, i.e. two VALU instructions per plane (v_cvt_f32_ubyteN + v_fma) instead of four. The
+// rounding of B (relative 2^-23 of a distance of at most the node extent when the ray starts near the node, covered by
+// the relative cull slack otherwise) is far inside the guard band the builders leave around every quantised plane
+// (at least 1/32 grid cell, bvh_build.cpp / bvh_gpu.hip). A zero direction component is replaced by +-2^-100 for the
+// box test only, so the slab of an axis-parallel ray is (-huge, +huge) inside, same-signed outside and [0, huge] on a
+// face — no 0*inf, no NaN — while the triangle test keeps the true direction. The far side is inflated (Ize 2013).
 struct RaySetup {
     f3 o, inv;
     bool sx, sy, sz;   // direction sign per axis: the NEAR plane of a slab is the upper one when set
 };
+SRD float box_dir(float d) { return fabsf(d) >= 7.888609e-31f ? d : copysignf(7.888609e-31f, d); }   // 2^-100
 SRD RaySetup ray_setup(f3 o, f3 d) {
     RaySetup r;
     r.o = o;
-    r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.inv = mk3(1.0f / box_dir(d.x), 1.0f / box_dir(d.y), 1.0f / box_dir(d.z));
     r.sx = (__float_as_uint(r.inv.x) >> 31) != 0u;
     r.sy = (__float_as_uint(r.inv.y) >> 31) != 0u;
     r.sz = (__float_as_uint(r.inv.z) >> 31) != 0u;
     return r;
 }
-// Decoded planes of one child: byte `c` of each plane dword, scaled onto the node's grid.
+// Byte `C` of a plane dword as a float: v_cvt_f32_ubyteC.
 template <int C>
-SRD float plane_of(uint32_t packed, float scale, float origin) {
-    return fmaf((float)((packed >> (8 * C)) & 0xFFu), scale, origin);   // v_cvt_f32_ubyteC + v_fma
-}
+SRD float plane_q(uint32_t packed) { return (float)((packed >> (8 * C)) & 0xFFu); }
 struct NodePlanes {
     uint32_t nx, ny, nz, fx, fy, fz;   // near / far plane dwords, already picked by the ray's signs
-    float sx, sy, sz;                  // grid steps 2^e
-    float ox, oy, oz;                  // node origin
+    float ax, ay, az;                  // 2^e * inv
+    float bx, by, bz;                  // (node origin - ray origin) * inv
 };
 template <int C>
-SRD bool child_hit(const NodePlanes& p, const RaySetup& r, float t_lo, float t_hi, float& tnear) {
-    const float t0 = fmaxf(fmaxf((plane_of<C>(p.nx, p.sx, p.ox) - r.o.x) * r.inv.x, (plane_of<C>(p.ny, p.sy, p.oy) - r.o.y) * r.inv.y),
-                           fmaxf((plane_of<C>(p.nz, p.sz, p.oz) - r.o.z) * r.inv.z, t_lo));
-    float far = fminf(fminf((plane_of<C>(p.fx, p.sx, p.ox) - r.o.x) * r.inv.x, (plane_of<C>(p.fy, p.sy, p.oy) - r.o.y) * r.inv.y),
-                      (plane_of<C>(p.fz, p.sz, p.oz) - r.o.z) * r.inv.z);
-    far = far * (1.0f + copysignf(5e-7f, far));  // away from zero; keeps +-inf (an fma form turns -inf into NaN)
+SRD bool child_hit(const NodePlanes& p, float t_lo, float t_hi, float& tnear) {
+    const float t0 = fmaxf(fmaxf(fmaf(plane_q<C>(p.nx), p.ax, p.bx), fmaf(plane_q<C>(p.ny), p.ay, p.by)),
+                           fmaxf(fmaf(plane_q<C>(p.nz), p.az, p.bz), t_lo));
+    float far = fminf(fminf(fmaf(plane_q<C>(p.fx), p.ax, p.bx), fmaf(plane_q<C>(p.fy), p.ay, p.by)), fmaf(plane_q<C>(p.fz), p.az, p.bz));
+    far = far * 1.0000005f;   // a negative far bound moves further away from every valid t > 0: harmless; +-inf stay
     tnear = t0;
     return t0 <= fminf(far, t_hi);
 }
@@ -156,7 +160,11 @@ SRD bool child_hit(const NodePlanes& p, const RaySetup& r, float t_lo, float t_h
 #define SR_PUSH(v) do { stack_base[sp * stride] = (v); sp++; } while (0)
 #define SR_POP() (sp == 0 ? kSentinel : stack_base[(--sp) * stride])
 
-SRD int pick(int4 c, uint32_t i) { return i == 0u ? c.x : (i == 1u ? c.y : (i == 2u ? c.z : c.w)); }
+SRD int pick(int4 c, uint32_t i) {   // two levels of selects (v_cndmask), no branches
+    const int lo = (i & 1u) ? c.y : c.x;
+    const int hi = (i & 1u) ? c.w : c.z;
+    return (i & 2u) ? hi : lo;
+}
 SRD void cswap(uint32_t& a, uint32_t& b) { const uint32_t lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
 
 template <bool ANY, bool STATS>
@@ -187,35 +195,37 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
             p.nx = rs.sx ? HX : LX; p.fx = rs.sx ? LX : HX;
             p.ny = rs.sy ? HY : LY; p.fy = rs.sy ? LY : HY;
             p.nz = rs.sz ? HZ : LZ; p.fz = rs.sz ? LZ : HZ;
-            p.sx = __uint_as_float((ex & 0xFFu) << 23); p.sy = __uint_as_float(((ex >> 8) & 0xFFu) << 23); p.sz = __uint_as_float(((ex >> 16) & 0xFFu) << 23);
-            p.ox = h0.x; p.oy = h0.y; p.oz = h0.z;
+            p.ax = __uint_as_float((ex & 0xFFu) << 23) * rs.inv.x; p.ay = __uint_as_float(((ex >> 8) & 0xFFu) << 23) * rs.inv.y;
+            p.az = __uint_as_float(((ex >> 16) & 0xFFu) << 23) * rs.inv.z;
+            p.bx = (h0.x - rs.o.x) * rs.inv.x; p.by = (h0.y - rs.o.y) * rs.inv.y; p.bz = (h0.z - rs.o.z) * rs.inv.z;
             float n0, n1, n2, n3;
-            const bool b0 = child_hit<0>(p, rs, t_lo, cull, n0);
-            const bool b1 = child_hit<1>(p, rs, t_lo, cull, n1);
-            const bool b2 = child_hit<2>(p, rs, t_lo, cull, n2);
-            const bool b3 = child_hit<3>(p, rs, t_lo, cull, n3);
+            const bool b0 = child_hit<0>(p, t_lo, cull, n0);
+            const bool b1 = child_hit<1>(p, t_lo, cull, n1);
+            const bool b2 = child_hit<2>(p, t_lo, cull, n2);
+            const bool b3 = child_hit<3>(p, t_lo, cull, n3);
+            // Continue with the nearest hit child (an existence query: with any hit child), push the other hit children.
+            // Pushes are branch-free: every child reference is stored at the current stack top and the top only
+            // advances for a child that is hit and not the one continued with (the launchers allocate one spare stack
+            // level for the store that does not advance). On average 1.2 children of a node are hit, so ordering the
+            // pushed ones as well (a full 4-key sorting network + per-key selects) costs more than it saves.
+            uint32_t k0, k1, k2, k3;
             if (ANY) {
-                // order is irrelevant for an existence query: continue with the first hit child, push the rest
-                int next = kSentinel;
-                bool have = false;
-                if (b0) { next = child.x; have = true; }
-                if (b1) { if (have) SR_PUSH(child.y); else { next = child.y; have = true; } }
-                if (b2) { if (have) SR_PUSH(child.z); else { next = child.z; have = true; } }
-                if (b3) { if (have) SR_PUSH(child.w); else { next = child.w; have = true; } }
-                node = have ? next : SR_POP();
+                k0 = b0 ? 0u : 0xFFFFFFFFu; k1 = b1 ? 1u : 0xFFFFFFFFu; k2 = b2 ? 2u : 0xFFFFFFFFu; k3 = b3 ? 3u : 0xFFFFFFFFu;
             } else {
-                // sort the hit children near-to-far: key = entry distance (clamped to >= 0, low 2 mantissa
-                // bits replaced by the child slot) — positive floats order like unsigned integers
-                uint32_t k0 = b0 ? ((__float_as_uint(fmaxf(n0, 0.0f)) & ~3u) | 0u) : 0xFFFFFFFFu;
-                uint32_t k1 = b1 ? ((__float_as_uint(fmaxf(n1, 0.0f)) & ~3u) | 1u) : 0xFFFFFFFFu;
-                uint32_t k2 = b2 ? ((__float_as_uint(fmaxf(n2, 0.0f)) & ~3u) | 2u) : 0xFFFFFFFFu;
-                uint32_t k3 = b3 ? ((__float_as_uint(fmaxf(n3, 0.0f)) & ~3u) | 3u) : 0xFFFFFFFFu;
-                cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
-                if (k3 != 0xFFFFFFFFu) SR_PUSH(pick(child, k3 & 3u));
-                if (k2 != 0xFFFFFFFFu) SR_PUSH(pick(child, k2 & 3u));
-                if (k1 != 0xFFFFFFFFu) SR_PUSH(pick(child, k1 & 3u));
-                node = (k0 != 0xFFFFFFFFu) ? pick(child, k0 & 3u) : SR_POP();
+                // key = entry distance (clamped to >= 0, low 2 mantissa bits replaced by the child slot): positive floats
+                // order like unsigned integers
+                k0 = b0 ? ((__float_as_uint(fmaxf(n0, 0.0f)) & ~3u) | 0u) : 0xFFFFFFFFu;
+                k1 = b1 ? ((__float_as_uint(fmaxf(n1, 0.0f)) & ~3u) | 1u) : 0xFFFFFFFFu;
+                k2 = b2 ? ((__float_as_uint(fmaxf(n2, 0.0f)) & ~3u) | 2u) : 0xFFFFFFFFu;
+                k3 = b3 ? ((__float_as_uint(fmaxf(n3, 0.0f)) & ~3u) | 3u) : 0xFFFFFFFFu;
             }
+            const uint32_t kmin = min(min(k0, k1), min(k2, k3));
+            const uint32_t slot = kmin & 3u;
+            stack_base[sp * stride] = child.x; sp += (b0 && k0 != kmin) ? 1 : 0;
+            stack_base[sp * stride] = child.y; sp += (b1 && k1 != kmin) ? 1 : 0;
+            stack_base[sp * stride] = child.z; sp += (b2 && k2 != kmin) ? 1 : 0;
+            stack_base[sp * stride] = child.w; sp += (b3 && k3 != kmin) ? 1 : 0;
+            node = (kmin != 0xFFFFFFFFu) ? pick(child, slot) : SR_POP();
         }
         if (node == kSentinel) break;
         // leaf

@@ -616,7 +616,7 @@ def test_device_lbvh_fast_build(rt, oracle, blue_noise, scene_fn, box):
     print("%s: %d tris, host SAH %.1f ms (%d nodes, stack %d) | device LBVH %.2f ms (%d nodes, depth %d, stack %d)" % (
         desc.name, st.n_triangles, sah.build_ms, sah.n_nodes, sah.max_stack, st.build_ms, st.n_nodes, st.max_depth, st.max_stack))
     nodes, tris = gsc.read_bvh()
-    _check_bvh(nodes, tris, st.max_depth, st.max_stack, stack_limit=48)
+    _check_bvh(nodes, tris, st.max_depth, st.max_stack, stack_limit=47)
     rays = np.concatenate([camera_rays(oracle, desc, 160, 90), random_rays(20000, 5, box=box)])
     rays_t = rt.rays_to_device(rays)
     hits_t = gsc.trace_closest(rays_t, len(rays))
@@ -638,7 +638,7 @@ def test_device_lbvh_fast_build(rt, oracle, blue_noise, scene_fn, box):
     assert gsc.as_state()[1] == abi.OP_UPDATE
     assert_bits_equal(osc.trace_closest(rays), rt.hits_from_device(gsc.trace_closest(rays_t, len(rays))), "SrHit (LBVH + update)")
     nodes, tris = gsc.read_bvh()
-    _check_bvh(nodes, tris, st.max_depth, st.max_stack, stack_limit=48)
+    _check_bvh(nodes, tris, st.max_depth, st.max_stack, stack_limit=47)
 
 
 def test_device_lbvh_1m_triangles(rt, oracle):

@@ -90,7 +90,7 @@ def _world_tris(desc):
     return np.concatenate(out).astype(np.float32)
 
 
-def _check_bvh(nodes, tris, max_depth, max_stack, stack_limit=32):
+def _check_bvh(nodes, tris, max_depth, max_stack, stack_limit=31):
     """Walks the 64-byte quantised 4-wide nodes exactly as the kernel decodes them (traverse.h)."""
     n = len(tris)
     seen = np.zeros(n, dtype=int)
