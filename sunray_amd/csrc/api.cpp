@@ -83,6 +83,11 @@ struct SrScene {
     DeviceBuffer d_shade_tex, d_mesh_tex, d_textures;
     // acceleration-structure maintenance (update in place): per-level node lists, exact node boxes, flatten inputs
     DeviceBuffer d_level_nodes, d_node_box, d_mesh_infos, d_flat_instances, d_scratch;
+    // cost-ordered tile schedules of the two passes (kernels.hip thread_pixel), one per launch geometry
+    struct TileSchedule { int which = -1; uint32_t width = 0, y0 = 0, y1 = 0; DeviceBuffer cost, order; bool have_order = false; uint64_t last_use = 0; };
+    std::vector<TileSchedule> schedules;
+    uint64_t schedule_clock = 0;
+    int tile_scheduling = 1;                // SR_TILE_SCHEDULING=0 in the environment disables it (A/B)
     uint32_t forced_op = SR_OP_NONE;        // sr_scene_force_next_op (test / bench hook)
     bool last_build_on_device = false;
     std::vector<uint32_t> level_offsets;
@@ -184,6 +189,7 @@ int sr_scene_create(int device, SrScene** out) {
     HIP_TRY(hipSetDevice(device));
     SrScene* s = new SrScene();
     s->device = device;
+    if (const char* ev = getenv("SR_TILE_SCHEDULING")) s->tile_scheduling = atoi(ev) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
     // counters (4 x u64) + queue head, in one small allocation of their own
@@ -204,6 +210,7 @@ int sr_scene_destroy(SrScene* s) {
     s->d_level_nodes.release(); s->d_node_box.release(); s->d_mesh_infos.release(); s->d_flat_instances.release(); s->d_scratch.release();
     s->d_nodes.release(); s->d_tris.release(); s->d_shade.release(); s->d_mesh_const.release(); s->d_slot_of_gid.release(); s->d_instances.release();
     s->d_lights.release(); s->d_misc.release();
+    for (auto& ts : s->schedules) { ts.cost.release(); ts.order.release(); }
     for (auto& pool : s->events) for (auto& e : pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete s;
     return SR_OK;
@@ -772,9 +779,35 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
     a.y0 = y0; a.y1 = y1;
     a.cfg = p->config;
     hipStream_t st = (hipStream_t)stream;
-    ScopedTiming tm(s, which == 0 ? kRis : kFinal, st);
-    int e = srk_launch_pass(a, which, s->instrumented, s->dev.shade_tex != nullptr, s->stack_entries, st);
+    // tile schedule of this launch geometry: order from the previous launch's costs, costs of this launch for the next
+    SrScene::TileSchedule* sched = nullptr;
+    if (s->tile_scheduling) {
+        for (auto& ts : s->schedules) if (ts.which == which && ts.width == p->width && ts.y0 == y0 && ts.y1 == y1) sched = &ts;
+        if (!sched) {
+            if (s->schedules.size() < 8) s->schedules.emplace_back();
+            sched = &s->schedules[0];
+            for (auto& ts : s->schedules) if (ts.which < 0 || ts.last_use < sched->last_use) sched = &ts;
+            if (sched->which >= 0) HIP_TRY(hipStreamSynchronize(st));          // recycling an entry a launch may still read
+            const size_t bytes = (size_t)srk_pass_tile_count(p->width, y1 - y0) * 4;
+            if ((rc = sched->cost.reserve(bytes)) != SR_OK || (rc = sched->order.reserve(bytes)) != SR_OK) return rc;
+            HIP_TRY(hipMemsetAsync(sched->cost.p, 0, bytes, st));
+            sched->which = which; sched->width = p->width; sched->y0 = y0; sched->y1 = y1; sched->have_order = false;
+        }
+        sched->last_use = ++s->schedule_clock;
+        a.tile_cost = (uint32_t*)sched->cost.p;
+        a.tile_order = sched->have_order ? (const uint32_t*)sched->order.p : nullptr;
+    }
+    int e;
+    {
+        ScopedTiming tm(s, which == 0 ? kRis : kFinal, st);      // times the pass kernel only
+        e = srk_launch_pass(a, which, s->instrumented, s->dev.shade_tex != nullptr, s->stack_entries, st);
+    }
     if (e != 0) return fail(SR_ERR_HIP, std::string(name) + " launch: " + hipGetErrorString((hipError_t)e));
+    if (sched) {
+        e = srk_launch_tile_order((const uint32_t*)sched->cost.p, (uint32_t*)sched->order.p, p->width, y1 - y0, st);
+        if (e != 0) return fail(SR_ERR_HIP, std::string(name) + " tile schedule: " + hipGetErrorString((hipError_t)e));
+        sched->have_order = true;
+    }
     return SR_OK;
 }
 
