@@ -41,6 +41,13 @@ def lib():
             raise ImportError(
                 "sunray_amd: %s is missing — build it with `python -m sunray_amd.build` (or "
                 "__graft_entry__.build()). There is no CPU fallback for the product path." % LIB_PATH)
+        # The harnesses hand torch tensors to the library, so both must talk to ONE HIP runtime. torch ships its own copy of
+        # libamdhip64; loading ours first would bring in /opt/rocm's as a second runtime (and the later one finds "no
+        # ROCm-capable device"). Importing torch first makes the dynamic linker reuse its runtime for this library.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.sr_last_error.restype = C.c_char_p
         _lib = L
