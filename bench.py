@@ -129,27 +129,40 @@ def main():
     st = scene.bvh_stats()
     frame = rt.DeviceFrame(W, H, blue_noise, device=device)
     cfg = abi.SrTraceConfig.reference()
-    per = (H + world - 1) // world
-    gathered = torch.empty(world * per * W, 4, dtype=torch.float32, device=device)
-    scratch = torch.zeros(per * W, 4, dtype=torch.float32, device=device)
+    import copy
+    bounds = None
+    if world > 1:
+        # Strip boundaries of equal estimated cost (sky rows are far cheaper than surface rows), from one uncounted RIS
+        # pass over the whole frame on a throwaway frame buffer: every rank computes the same profile, so the cut needs
+        # no communication, and it is frozen before frame 0 (a rank owns the temporal history of its rows + halo).
+        cal = rt.DeviceFrame(W, H, blue_noise, device=device)
+        ccfg = copy.copy(cfg)
+        ccfg.flags = cfg.flags | abi.TRACE_FLAG_UNCOUNTED
+        scene.trace_ris(cal, rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, None), 0, ccfg)
+        torch.cuda.synchronize()
+        depth = cal.depth.cpu().numpy().view(np.uint16)
+        bounds = sd.balanced_bounds(sd.row_cost_from_depth(depth, W, H), world)
+        del cal
+    # the gather of frame f overlaps the tracing of frame f+1 (RCCL runs on its own stream); rehearsal: gloo on host copies
+    pipe = sd.GatherPipeline(W, H, world, rank, "cpu" if rehearsal else device, bounds=bounds) if world > 1 else None
 
     state = {"prev": None, "frame": 0}
 
     def step():
         m = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, state["prev"])
         state["prev"] = list(m.view_proj)
-        sd.render_strip(scene, frame, m, state["frame"], cfg, world, rank, abi.TRACE_FLAG_UNCOUNTED)
+        sd.render_strip(scene, frame, m, state["frame"], cfg, world, rank, abi.TRACE_FLAG_UNCOUNTED, bounds=bounds)
         if world > 1:
             if rehearsal:
                 torch.cuda.synchronize()
-                full = sd.gather_strips(frame.raw_color.cpu(), W, H, world, rank)
-                gathered[: H * W].copy_(full)
+                pipe.submit(frame.raw_color.cpu())
             else:
-                sd.gather_strips(frame.raw_color, W, H, world, rank, out=gathered, scratch=scratch)
+                pipe.submit(frame.raw_color)
         state["frame"] += 1
 
     def fence():
         if world > 1:
+            pipe.wait()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -161,8 +174,7 @@ def main():
     scene.set_instrumented(True)
     per_kind = {}
     m_i = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, state["prev"])
-    y0, h = sd.strip_rows(H, world, rank)
-    import copy
+    y0, h = (bounds[rank], bounds[rank + 1] - bounds[rank]) if bounds is not None else sd.strip_rows(H, world, rank)
     halo_cfg = copy.copy(cfg)
     halo_cfg.flags = cfg.flags | abi.TRACE_FLAG_UNCOUNTED
     scene.reset_counters()
@@ -204,7 +216,7 @@ def main():
     # CRC of the last frame's full fp32 radiance image (outside the timed region): N-GPU runs of the same
     # --steps/--warmup must print the same value as the 1-GPU run (tiling is bit-exact).
     import zlib
-    final_image = gathered[: H * W] if world > 1 else frame.raw_color
+    final_image = pipe.image() if world > 1 else frame.raw_color
     frame_crc = "%08x" % (zlib.crc32(final_image.cpu().numpy().tobytes()) & 0xFFFFFFFF)
 
     if rank == 0:
@@ -238,7 +250,9 @@ def main():
                 "rays_per_frame": total_rays / args.steps,
                 "closest_per_frame": total_closest / args.steps,
                 "any_per_frame": total_any / args.steps,
-                "parallelism": "rows split into %d strips, RIS halo %d rows recomputed, radiance all-gathered over RCCL" % (world, sd.SPATIAL_HALO) if world > 1 else "single GPU",
+                "parallelism": ("rows split into %d cost-balanced strips %s, RIS halo %d rows recomputed, radiance strips all-gathered over RCCL "
+                                "asynchronously (frame f's gather overlaps frame f+1)" % (world, [bounds[i + 1] - bounds[i] for i in range(world)], sd.SPATIAL_HALO))
+                               if world > 1 else "single GPU",
                 "bvh_build_ms_host": st.build_ms,
                 "last_frame_crc32": frame_crc,
             },

@@ -25,6 +25,40 @@ def strip_rows(height, world, rank):
     return y0, min(per, height - y0)
 
 
+def balanced_bounds(row_cost, world, min_rows=8, max_share=1.5):
+    """Cuts the rows into `world` contiguous strips of (nearly) equal summed cost: returns world+1 increasing row
+    boundaries. Strips are cut one after the other, each taking 1/n of the cost that is left for the n ranks that are
+    left, with at least `min_rows` rows and at most max_share * height / world rows (the gather pads every strip to the
+    tallest one, so a very tall cheap strip would inflate the collective). Deterministic: every rank that feeds the
+    same profile gets the same cut, so no communication is needed to agree on it."""
+    import numpy as np
+    cost = np.maximum(np.asarray(row_cost, dtype=np.float64), 0.0) + 1e-12
+    height = len(cost)
+    min_rows = max(1, min(min_rows, height // max(world, 1)))
+    max_rows = max(int(np.ceil(max_share * height / max(world, 1))), min_rows)
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    bounds = [0]
+    for k in range(world - 1):
+        y, n = bounds[-1], world - k
+        target = cum[y] + (cum[-1] - cum[y]) / n
+        cut = int(np.searchsorted(cum, target, side="left"))
+        cut = min(max(cut, y + min_rows), y + max_rows)          # this strip: [min_rows, max_rows] rows
+        cut = max(cut, height - (n - 1) * max_rows)              # the ranks that are left can still cover the rest ...
+        cut = min(cut, height - (n - 1) * min_rows)              # ... and each gets its minimum
+        bounds.append(max(cut, y))
+    bounds.append(height)
+    return [int(v) for v in bounds]
+
+
+def row_cost_from_depth(depth_u16, width, height, sky_weight=1.0, surface_weight=4.0):
+    """Per-row cost estimate from a G-buffer depth image (R16F bits): a sky pixel (depth +inf, ray_gen_ris.slang:168)
+    costs one primary ray per pass, a surface pixel the whole ReSTIR sequence (~6 rays, mostly incoherent)."""
+    import numpy as np
+    d = np.asarray(depth_u16).reshape(height, width)
+    sky = (d & 0x7FFF) >= 0x7C00
+    return sky_weight * sky.sum(axis=1) + surface_weight * (~sky).sum(axis=1)
+
+
 def halo_bands(height, y0, h, halo=SPATIAL_HALO):
     """Row bands outside [y0, y0+h) within `halo` rows of it, clipped to the image."""
     bands = []
@@ -39,12 +73,14 @@ def halo_bands(height, y0, h, halo=SPATIAL_HALO):
     return bands
 
 
-def render_strip(scene, frame, matrices, frame_count, cfg, world, rank, uncounted_flag=1):
+def render_strip(scene, frame, matrices, frame_count, cfg, world, rank, uncounted_flag=1, bounds=None):
     """Traces this rank's part of one frame into the full-size buffers of `frame`.
 
     `scene` is a sunray_amd.runtime.Scene (GPU) — or, in the CPU tests, the oracle's scene: both offer
-    trace_ris / trace_final(frame, matrices, frame_count, cfg, tile=(y0, h))."""
-    y0, h = strip_rows(frame.height, world, rank)
+    trace_ris / trace_final(frame, matrices, frame_count, cfg, tile=(y0, h)). `bounds` (balanced_bounds) replaces
+    the equal split; it must stay the same for the whole frame sequence (a rank keeps the temporal history of
+    exactly its rows + halo)."""
+    y0, h = (bounds[rank], bounds[rank + 1] - bounds[rank]) if bounds is not None else strip_rows(frame.height, world, rank)
     if h <= 0:
         return y0, h
     if cfg.enable_restir:
@@ -77,3 +113,58 @@ def gather_strips(raw_color, width, height, world, rank, out=None, scratch=None)
     else:
         out.copy_(scratch)
     return out[: height * width]
+
+
+class GatherPipeline:
+    """Asynchronous, double-buffered gather of the radiance strips: the collective of frame f runs on the collective
+    library's own stream while the kernels of frame f+1 are already tracing (xGMI transfer hidden behind compute).
+    Strips may have different heights (balanced_bounds): every rank contributes a buffer padded to the tallest strip,
+    one `all_gather_into_tensor` per frame, and `image()` reassembles the rows.
+
+    submit(raw_color) copies this rank's strip out of the frame buffer (so the next frame may overwrite it) and starts
+    the collective; wait(slot) makes the current stream wait for it. At most `depth` gathers are in flight."""
+
+    def __init__(self, width, height, world, rank, device, bounds=None, depth=2, dtype=None):
+        import torch
+        self.torch = torch
+        self.width, self.height, self.world, self.rank = width, height, world, rank
+        self.bounds = list(bounds) if bounds is not None else [min(r * ((height + world - 1) // world), height) for r in range(world)] + [height]
+        self.rows_max = max(self.bounds[r + 1] - self.bounds[r] for r in range(world))
+        dtype = dtype or torch.float32
+        n = self.rows_max * width
+        self.send = [torch.zeros(n, 4, dtype=dtype, device=device) for _ in range(depth)]
+        self.recv = [torch.empty(world * n, 4, dtype=dtype, device=device) for _ in range(depth)]
+        self.work = [None] * depth
+        self.next = 0
+        self.last = None
+
+    def submit(self, raw_color, all_gather=None):
+        import torch.distributed as dist
+        k = self.next
+        self.wait(k)                                   # the slot's previous gather must be done before its buffers are reused
+        y0, y1 = self.bounds[self.rank], self.bounds[self.rank + 1]
+        if y1 > y0:
+            self.send[k][: (y1 - y0) * self.width].copy_(raw_color[y0 * self.width:y1 * self.width])
+        if self.world > 1:
+            fn = all_gather or (lambda out, inp: dist.all_gather_into_tensor(out, inp, async_op=True))
+            self.work[k] = fn(self.recv[k], self.send[k])
+        else:
+            self.recv[k].copy_(self.send[k])
+        self.last = k
+        self.next = (k + 1) % len(self.send)
+        return k
+
+    def wait(self, k=None):
+        ks = range(len(self.work)) if k is None else [k]
+        for i in ks:
+            if self.work[i] is not None:
+                self.work[i].wait()
+                self.work[i] = None
+
+    def image(self, k=None):
+        """Full [H*W, 4] image of slot k (default: the last submitted), rows re-assembled from the padded strips."""
+        k = self.last if k is None else k
+        self.wait(k)
+        n = self.rows_max * self.width
+        parts = [self.recv[k][r * n: r * n + (self.bounds[r + 1] - self.bounds[r]) * self.width] for r in range(self.world)]
+        return self.torch.cat(parts, dim=0)

@@ -34,17 +34,28 @@ def _worker(rank, world, port, W, H, frames, out_dir):
     cfg = abi.SrTraceConfig.reference()
     prev = None
     images = []
+    # uneven, cost-balanced strips + the double-buffered asynchronous gather bench.py uses (gloo works on host tensors)
+    bounds = sd.balanced_bounds(np.concatenate([np.ones(H // 2), np.full(H - H // 2, 3.0)]), world, min_rows=4)
+    assert bounds[0] == 0 and bounds[-1] == H and bounds[1] > H // 2      # the cheap top half makes the first strip taller
+    pipe = sd.GatherPipeline(W, H, world, rank, "cpu", bounds=bounds)
+    pending = []
     for f in range(frames):
         m = ob.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, prev)
         prev = list(m.view_proj)
         s.reset_counters()
-        sd.render_strip(s, fr, m, f, cfg, world, rank)
-        full = sd.gather_strips(torch.from_numpy(fr.raw_color), W, H, world, rank)
-        images.append(full.numpy().copy())
+        sd.render_strip(s, fr, m, f, cfg, world, rank, bounds=bounds)
+        pending.append(pipe.submit(torch.from_numpy(fr.raw_color)))        # frame f's gather is in flight while f+1 is traced
+        if len(pending) == 2:
+            images.append(pipe.image(pending.pop(0)).numpy().copy())
+        # the synchronous equal-split helper still gathers the same strips when asked to
+        if f == 0:
+            assert sd.gather_strips(torch.from_numpy(fr.raw_color), W, H, world, rank).shape == (H * W, 4)
         # max-over-ranks reduction used for timing in bench.py
         t = torch.tensor([float(rank + 1)])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert t.item() == float(world)
+    while pending:
+        images.append(pipe.image(pending.pop(0)).numpy().copy())
     dist.barrier()
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.stack(images))
     dist.destroy_process_group()
@@ -60,6 +71,17 @@ def test_strip_helpers():
     assert sd.halo_bands(1080, 945, 135) == [(915, 30)]
     assert sd.halo_bands(40, 10, 10) == [(0, 10), (20, 20)]
     assert sd.halo_bands(40, 40, 0) == []
+    # cost-balanced cuts: equal cost -> equal strips; a cheap top third -> taller first strips, capped at 1.5x the equal share
+    assert sd.balanced_bounds(np.ones(1080), 8) == [0, 136, 271, 406, 541, 676, 811, 946, 1080]
+    cost = np.concatenate([np.full(300, 1.0), np.full(780, 4.0)])
+    b = sd.balanced_bounds(cost, 8)
+    heights = [b[i + 1] - b[i] for i in range(8)]
+    assert b[0] == 0 and b[-1] == 1080 and all(h >= 8 for h in heights) and max(heights) <= 203
+    shares = [cost[b[i]:b[i + 1]].sum() for i in range(8)]
+    assert max(shares) / np.mean(shares) < 1.1 < (4.0 * 135) / (cost.sum() / 8)       # equal rows would be 26 % off
+    assert sd.balanced_bounds(np.zeros(10), 4) == [0, 3, 6, 8, 10] and sd.balanced_bounds(np.ones(5), 8)[-1] == 5
+    depth = np.full((4, 6), 0x7C00, dtype=np.uint16); depth[2:] = 0x4000
+    assert list(sd.row_cost_from_depth(depth, 6, 4)) == [6.0, 6.0, 24.0, 24.0]
 
 
 @pytest.mark.timeout(300)
