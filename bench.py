@@ -132,32 +132,52 @@ def main():
     import copy
     bounds = None
     if world > 1:
-        # Strip boundaries of equal estimated cost (sky rows are far cheaper than surface rows), from one uncounted RIS
-        # pass over the whole frame on a throwaway frame buffer: every rank computes the same profile, so the cut needs
-        # no communication, and it is frozen before frame 0 (a rank owns the temporal history of its rows + halo).
+        # Strip boundaries of equal MEASURED cost (sky rows are far cheaper than surface rows, rows near the horizon the most
+        # expensive), from a few uncounted whole-frame frames on a throwaway frame buffer. The cut is frozen before frame 0
+        # (a rank owns the temporal history of its rows + halo); all ranks must agree on it, so rank 0's cut is broadcast.
         cal = rt.DeviceFrame(W, H, blue_noise, device=device)
         ccfg = copy.copy(cfg)
         ccfg.flags = cfg.flags | abi.TRACE_FLAG_UNCOUNTED
-        scene.trace_ris(cal, rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, None), 0, ccfg)
-        torch.cuda.synchronize()
-        depth = cal.depth.cpu().numpy().view(np.uint16)
-        bounds = sd.balanced_bounds(sd.row_cost_from_depth(depth, W, H), world)
+        cprev = None
+        for f in range(4):      # a few frames: the final pass's visibility rays appear as the reservoirs fill up
+            cm = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, cprev)
+            cprev = list(cm.view_proj)
+            scene.trace_ris(cal, cm, f, ccfg)
+            scene.trace_final(cal, cm, f, ccfg)
+        # measured cycles per tile row of both passes (the data behind the library's tile schedule), spread over pixel rows
+        tile_rows = scene.tile_row_costs(0, W, 0, H) + scene.tile_row_costs(1, W, 0, H)
+        row_cost = np.repeat(tile_rows / 8.0, 8)[:H]
+        bounds = sd.balanced_bounds(row_cost, world)
         del cal
+        blist = [bounds]
+        dist.broadcast_object_list(blist, src=0)      # cycle counts differ a little from GPU to GPU: take rank 0's cut
+        bounds = [int(v) for v in blist[0]]
     # the gather of frame f overlaps the tracing of frame f+1 (RCCL runs on its own stream); rehearsal: gloo on host copies
     pipe = sd.GatherPipeline(W, H, world, rank, "cpu" if rehearsal else device, bounds=bounds) if world > 1 else None
 
-    state = {"prev": None, "frame": 0}
+    state = {"prev": None, "frame": 0, "last": frame}
+    # Two frames in flight per GPU (RIS of frame f+1 overlaps the draining final pass of frame f): a rank's share of a frame
+    # is about one round of waves, i.e. latency-bound on its own. On by default for N > 1; N = 1 runs the passes back to
+    # back so that the per-launch durations behind `roofline` are those of undisturbed kernels.
+    pipelined = os.environ.get("SUNRAY_BENCH_PIPELINE", "1" if world > 1 else "0") == "1"
+    fpipe = sd.FramePipeline(frame, rt.DeviceFrame(W, H, blue_noise, device=device)) if pipelined else None
+
+    def submit_gather(fr):
+        if world > 1:
+            if rehearsal:
+                torch.cuda.current_stream().synchronize()
+                pipe.submit(fr.raw_color.cpu())
+            else:
+                pipe.submit(fr.raw_color)
 
     def step():
         m = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, state["prev"])
         state["prev"] = list(m.view_proj)
-        sd.render_strip(scene, frame, m, state["frame"], cfg, world, rank, abi.TRACE_FLAG_UNCOUNTED, bounds=bounds)
-        if world > 1:
-            if rehearsal:
-                torch.cuda.synchronize()
-                pipe.submit(frame.raw_color.cpu())
-            else:
-                pipe.submit(frame.raw_color)
+        if fpipe is not None:
+            state["last"] = fpipe.step(scene, m, state["frame"], cfg, world, rank, bounds=bounds, after_final=submit_gather)
+        else:
+            sd.render_strip(scene, frame, m, state["frame"], cfg, world, rank, abi.TRACE_FLAG_UNCOUNTED, bounds=bounds)
+            submit_gather(frame)
         state["frame"] += 1
 
     def fence():
@@ -177,14 +197,15 @@ def main():
     y0, h = (bounds[rank], bounds[rank + 1] - bounds[rank]) if bounds is not None else sd.strip_rows(H, world, rank)
     halo_cfg = copy.copy(cfg)
     halo_cfg.flags = cfg.flags | abi.TRACE_FLAG_UNCOUNTED
+    iframe = fpipe.frames[state["frame"] & 1] if fpipe is not None else frame
     scene.reset_counters()
-    scene.trace_ris(frame, m_i, state["frame"], cfg, tile=(y0, h))
+    scene.trace_ris(iframe, m_i, state["frame"], cfg, tile=(y0, h))
     per_kind[KIND_RIS] = scene.counters()
     if world > 1:   # keep the halo rows' reservoirs current: they are next frame's temporal history
         for band in sd.halo_bands(H, y0, h):
-            scene.trace_ris(frame, m_i, state["frame"], halo_cfg, tile=band)
+            scene.trace_ris(iframe, m_i, state["frame"], halo_cfg, tile=band)
     scene.reset_counters()
-    scene.trace_final(frame, m_i, state["frame"], cfg, tile=(y0, h))
+    scene.trace_final(iframe, m_i, state["frame"], cfg, tile=(y0, h))
     per_kind[KIND_FINAL] = scene.counters()
     state["prev"] = list(m_i.view_proj)
     state["frame"] += 1
@@ -216,7 +237,7 @@ def main():
     # CRC of the last frame's full fp32 radiance image (outside the timed region): N-GPU runs of the same
     # --steps/--warmup must print the same value as the 1-GPU run (tiling is bit-exact).
     import zlib
-    final_image = pipe.image() if world > 1 else frame.raw_color
+    final_image = pipe.image() if world > 1 else state["last"].raw_color
     frame_crc = "%08x" % (zlib.crc32(final_image.cpu().numpy().tobytes()) & 0xFFFFFFFF)
 
     if rank == 0:
@@ -253,6 +274,7 @@ def main():
                 "parallelism": ("rows split into %d cost-balanced strips %s, RIS halo %d rows recomputed, radiance strips all-gathered over RCCL "
                                 "asynchronously (frame f's gather overlaps frame f+1)" % (world, [bounds[i + 1] - bounds[i] for i in range(world)], sd.SPATIAL_HALO))
                                if world > 1 else "single GPU",
+                "frames_in_flight": 2 if pipelined else 1,
                 "bvh_build_ms_host": st.build_ms,
                 "last_frame_crc32": frame_crc,
             },

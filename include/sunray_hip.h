@@ -193,7 +193,8 @@ typedef struct SrTraceConfig {
                                  plain NEE branch (ray_gen_final.slang:328-382); the RIS pass is not
                                  needed (BASELINE.json configs 2, 3, 5).                           */
     uint32_t flags;           /* SR_TRACE_FLAG_* */
-    uint32_t _reserved[2];
+    uint32_t count_y0;        /* with count_rows != 0: only pixels of rows [count_y0, count_y0 + count_rows) add  */
+    uint32_t count_rows;      /* their rays to the scene's counters — a strip traced together with its halo rows  */
 } SrTraceConfig;
 
 /* Do not add this launch's rays to the scene's ray counters: used for the halo rows a GPU re-traces
@@ -537,6 +538,12 @@ int sr_renderer_get(SrRenderer* renderer, SrScene** scene, const uint32_t** outp
 /* Stand-in for the reference's embedded 128x128 blue-noise PNG (lib.rs:281-309; an input asset, not
  * copied): hashed white noise, RGBA8, grey in rgb, alpha 255. Host pointer, w*h*4 bytes. */
 int sr_default_noise_texture(uint32_t w, uint32_t h, uint32_t seed, uint8_t* out_rgba8);
+
+/* Measured cost of the last launch of pass `which` (0 = raytracing_ris, 1 = raytracing_final) with this launch
+ * geometry, summed per tile row (8 pixel rows), in shader cycles: the data the library's own tile schedule uses.
+ * A tile-parallel host cuts its strips of equal cost from it (sunray_amd/distributed.py). out: cap doubles. */
+int sr_scene_read_tile_row_costs(SrScene* scene, int which, uint32_t width, uint32_t y0, uint32_t rows, double* out,
+                                 uint32_t cap, uint32_t* n_tile_rows);
 
 /* Ray counters since the last reset (device-side atomics, read back synchronously). */
 int sr_scene_reset_counters(SrScene* scene, void* stream);

@@ -609,11 +609,18 @@ void run_pass(Scene& s, const SrRtParams& p, F pixel_fn) {
 #pragma omp parallel
     {
         Ctx cx{s, p, Counters{}, s.num_lights()};
+        Counters mine;
 #pragma omp for schedule(dynamic, 1)
-        for (int64_t y = y0; y < (int64_t)y1; y++)
+        for (int64_t y = y0; y < (int64_t)y1; y++) {
+            cx.c = Counters{};
             for (uint32_t x = 0; x < p.width; x++) pixel_fn(cx, x, (uint32_t)y);
+            // SR_TRACE_FLAG_UNCOUNTED / count_y0, count_rows: halo rows do not count (include/sunray_hip.h)
+            const bool counted = !(p.config.flags & SR_TRACE_FLAG_UNCOUNTED) &&
+                                 (p.config.count_rows == 0u || ((uint32_t)y - p.config.count_y0) < p.config.count_rows);
+            if (counted) { mine.closest += cx.c.closest; mine.any += cx.c.any; mine.boxes += cx.c.boxes; mine.tris += cx.c.tris; }
+        }
 #pragma omp critical
-        { total.closest += cx.c.closest; total.any += cx.c.any; total.boxes += cx.c.boxes; total.tris += cx.c.tris; }
+        { total.closest += mine.closest; total.any += mine.any; total.boxes += mine.boxes; total.tris += mine.tris; }
     }
     s.counters.closest += total.closest; s.counters.any += total.any;
     s.counters.boxes += total.boxes; s.counters.tris += total.tris;

@@ -811,6 +811,30 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
     return SR_OK;
 }
 
+// Measured cost (shader cycles summed over the tiles of each 8-pixel tile row) of the last launch of pass `which` with
+// this geometry: what the tile schedule is derived from; tile-parallel hosts use it to cut strips of equal cost.
+int sr_scene_read_tile_row_costs(SrScene* s, int which, uint32_t width, uint32_t y0, uint32_t rows, double* out, uint32_t cap, uint32_t* n_tile_rows) {
+    if (!s || !out || !n_tile_rows) return fail(SR_ERR_INVALID_ARG, "sr_scene_read_tile_row_costs: null argument");
+    SrScene::TileSchedule* sched = nullptr;
+    for (auto& ts : s->schedules) if (ts.which == which && ts.width == width && ts.y0 == y0 && ts.y1 == y0 + rows) sched = &ts;
+    if (!sched) return fail(SR_ERR_STATE, "sr_scene_read_tile_row_costs: no launch of this pass with this geometry yet");
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    const uint32_t n_tiles = srk_pass_tile_count(width, rows);
+    const uint32_t tiles_y = srk_pass_tile_count(1, rows), tiles_x = n_tiles / std::max(tiles_y, 1u);
+    *n_tile_rows = tiles_y;
+    if (cap < tiles_y) return fail(SR_ERR_INVALID_ARG, "sr_scene_read_tile_row_costs: output too small");
+    std::vector<uint32_t> cost(n_tiles);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(cost.data(), sched->cost.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < tiles_y; r++) out[r] = 0.0;
+    for (uint32_t xcd = 0; xcd < 8; xcd++) {                    // band-major layout of thread_pixel (kernels.hip)
+        const uint32_t bx0 = (tiles_x * xcd) >> 3, bx1 = (tiles_x * (xcd + 1u)) >> 3, bw = bx1 - bx0;
+        for (uint32_t t = 0; t < bw * tiles_y; t++) out[t / bw] += (double)cost[(size_t)bx0 * tiles_y + t];
+    }
+    return SR_OK;
+}
+
 int sr_trace_ris(const SrRtParams* params, void* stream) { return run_pass(params, 0, stream); }
 int sr_trace_final(const SrRtParams* params, void* stream) { return run_pass(params, 1, stream); }
 

@@ -481,9 +481,10 @@ __global__ __launch_bounds__(kPassBlock, SR_RIS_WAVES) void ris_kernel(const Pas
     }
     record_tile_cost(a, cost_slot, t_start);
     if (!(a.cfg.flags & SR_TRACE_FLAG_UNCOUNTED)) {
-        flush_counter(sc.counters + 0, cx.n_closest);
-        flush_counter(sc.counters + 1, cx.n_any);
-        if (V & 1) { flush_counter(sc.counters + 2, cx.st.boxes); flush_counter(sc.counters + 3, cx.st.tris); }
+        const bool counted = a.cfg.count_rows == 0u || (py - a.cfg.count_y0) < a.cfg.count_rows;   // per lane: its pixel's row
+        flush_counter(sc.counters + 0, counted ? cx.n_closest : 0u);
+        flush_counter(sc.counters + 1, counted ? cx.n_any : 0u);
+        if (V & 1) { flush_counter(sc.counters + 2, counted ? cx.st.boxes : 0u); flush_counter(sc.counters + 3, counted ? cx.st.tris : 0u); }
     }
 }
 
@@ -749,9 +750,10 @@ __global__ __launch_bounds__(kPassBlock, SR_FINAL_WAVES) void final_kernel(const
     }
     record_tile_cost(a, cost_slot, t_start);
     if (!(a.cfg.flags & SR_TRACE_FLAG_UNCOUNTED)) {
-        flush_counter(sc.counters + 0, cx.n_closest);
-        flush_counter(sc.counters + 1, cx.n_any);
-        if (V & 1) { flush_counter(sc.counters + 2, cx.st.boxes); flush_counter(sc.counters + 3, cx.st.tris); }
+        const bool counted = a.cfg.count_rows == 0u || (py - a.cfg.count_y0) < a.cfg.count_rows;   // per lane: its pixel's row
+        flush_counter(sc.counters + 0, counted ? cx.n_closest : 0u);
+        flush_counter(sc.counters + 1, counted ? cx.n_any : 0u);
+        if (V & 1) { flush_counter(sc.counters + 2, counted ? cx.st.boxes : 0u); flush_counter(sc.counters + 3, counted ? cx.st.tris : 0u); }
     }
 }
 

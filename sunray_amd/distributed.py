@@ -25,7 +25,7 @@ def strip_rows(height, world, rank):
     return y0, min(per, height - y0)
 
 
-def balanced_bounds(row_cost, world, min_rows=8, max_share=1.5):
+def balanced_bounds(row_cost, world, min_rows=8, max_share=2.5):
     """Cuts the rows into `world` contiguous strips of (nearly) equal summed cost: returns world+1 increasing row
     boundaries. Strips are cut one after the other, each taking 1/n of the cost that is left for the n ranks that are
     left, with at least `min_rows` rows and at most max_share * height / world rows (the gather pads every strip to the
@@ -73,6 +73,34 @@ def halo_bands(height, y0, h, halo=SPATIAL_HALO):
     return bands
 
 
+def _strip(height, world, rank, bounds):
+    return (bounds[rank], bounds[rank + 1] - bounds[rank]) if bounds is not None else strip_rows(height, world, rank)
+
+
+def trace_ris_strip(scene, frame, matrices, frame_count, cfg, world, rank, bounds=None):
+    """The RIS pass of this rank's strip. With world > 1 it is ONE launch over the strip and its halo rows: a rank's share
+    of a frame is small, so every extra launch adds a tail in which the GPU drains; only the strip's own rows count
+    their rays (SrTraceConfig.count_y0 / count_rows)."""
+    y0, h = _strip(frame.height, world, rank, bounds)
+    if h <= 0 or not cfg.enable_restir:
+        return
+    if world > 1:
+        bands = halo_bands(frame.height, y0, h)
+        r0 = min([y0] + [b[0] for b in bands])
+        r1 = max([y0 + h] + [b[0] + b[1] for b in bands])
+        rcfg = copy.copy(cfg)
+        rcfg.count_y0, rcfg.count_rows = y0, h
+        scene.trace_ris(frame, matrices, frame_count, rcfg, tile=(r0, r1 - r0))
+    else:
+        scene.trace_ris(frame, matrices, frame_count, cfg, tile=(y0, h))
+
+
+def trace_final_strip(scene, frame, matrices, frame_count, cfg, world, rank, bounds=None):
+    y0, h = _strip(frame.height, world, rank, bounds)
+    if h > 0:
+        scene.trace_final(frame, matrices, frame_count, cfg, tile=(y0, h))
+
+
 def render_strip(scene, frame, matrices, frame_count, cfg, world, rank, uncounted_flag=1, bounds=None):
     """Traces this rank's part of one frame into the full-size buffers of `frame`.
 
@@ -80,18 +108,44 @@ def render_strip(scene, frame, matrices, frame_count, cfg, world, rank, uncounte
     trace_ris / trace_final(frame, matrices, frame_count, cfg, tile=(y0, h)). `bounds` (balanced_bounds) replaces
     the equal split; it must stay the same for the whole frame sequence (a rank keeps the temporal history of
     exactly its rows + halo)."""
-    y0, h = (bounds[rank], bounds[rank + 1] - bounds[rank]) if bounds is not None else strip_rows(frame.height, world, rank)
-    if h <= 0:
-        return y0, h
-    if cfg.enable_restir:
-        scene.trace_ris(frame, matrices, frame_count, cfg, tile=(y0, h))
-        if world > 1:
-            hcfg = copy.copy(cfg)
-            hcfg.flags = cfg.flags | uncounted_flag
-            for band in halo_bands(frame.height, y0, h):
-                scene.trace_ris(frame, matrices, frame_count, hcfg, tile=band)
-    scene.trace_final(frame, matrices, frame_count, cfg, tile=(y0, h))
-    return y0, h
+    trace_ris_strip(scene, frame, matrices, frame_count, cfg, world, rank, bounds)
+    trace_final_strip(scene, frame, matrices, frame_count, cfg, world, rank, bounds)
+    return _strip(frame.height, world, rank, bounds)
+
+
+class FramePipeline:
+    """Two frames in flight on one GPU: raytracing_ris of frame f+1 runs on its own stream while raytracing_final of frame
+    f still drains, so the tail of one launch is filled by the head of the next (the reference keeps
+    MAX_FRAMES_IN_FLIGHT = 2 frames in flight as well, src/lib.rs:71). What makes it legal: the RIS pass only WRITES the
+    G-buffer images and the current reservoir buffers and only READS the previous frame's reservoirs; the final pass
+    reads the G-buffer and the current reservoirs. With the G-buffer double-buffered (two frame objects that share
+    their reservoir arrays) the only orderings left are RIS(f) -> final(f), RIS(f) -> RIS(f+1) and final(f-2) -> RIS(f).
+    Results are those of sequential execution, bit for bit."""
+
+    def __init__(self, frame_a, frame_b):
+        import torch
+        frame_b.reservoirs, frame_b.reservoirs_gi = frame_a.reservoirs, frame_a.reservoirs_gi
+        self.frames = [frame_a, frame_b]
+        self.s_ris, self.s_final = torch.cuda.Stream(), torch.cuda.Stream()
+        self.ev_ris = [torch.cuda.Event(), torch.cuda.Event()]
+        self.ev_final = [torch.cuda.Event(), torch.cuda.Event()]
+        self.torch = torch
+
+    def step(self, scene, matrices, frame_count, cfg, world, rank, bounds=None, after_final=None):
+        torch = self.torch
+        k = frame_count & 1
+        fr = self.frames[k]
+        with torch.cuda.stream(self.s_ris):
+            self.s_ris.wait_event(self.ev_final[k])          # final(f-2) has finished reading this G-buffer
+            trace_ris_strip(scene, fr, matrices, frame_count, cfg, world, rank, bounds)
+            self.ev_ris[k].record(self.s_ris)
+        with torch.cuda.stream(self.s_final):
+            self.s_final.wait_event(self.ev_ris[k])
+            trace_final_strip(scene, fr, matrices, frame_count, cfg, world, rank, bounds)
+            self.ev_final[k].record(self.s_final)
+            if after_final is not None:
+                after_final(fr)                               # e.g. GatherPipeline.submit(fr.raw_color), on the final stream
+        return fr
 
 
 def gather_strips(raw_color, width, height, world, rank, out=None, scratch=None):

@@ -189,6 +189,14 @@ class Scene:
             xf = np.zeros((1, 12), dtype=np.float32)
         check(lib().sr_scene_set_instances(self._h, _p(keys), _p(counts), C.c_uint32(len(keys)), _p(np.ascontiguousarray(xf))))
 
+    def tile_row_costs(self, which, width, y0, rows):
+        """Measured cycles per 8-pixel tile row of the last launch of pass `which` (0 ris, 1 final) with this geometry."""
+        out = np.zeros((rows + 7) // 8 + 1, dtype=np.float64)
+        n = C.c_uint32()
+        check(lib().sr_scene_read_tile_row_costs(self._h, C.c_int(which), C.c_uint32(width), C.c_uint32(y0), C.c_uint32(rows), _p(out),
+                                                 C.c_uint32(len(out)), C.byref(n)))
+        return out[:n.value]
+
     def force_next_op(self, op):
         check(lib().sr_scene_force_next_op(self._h, C.c_uint32(op)))
 
