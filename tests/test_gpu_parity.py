@@ -203,6 +203,39 @@ def test_texture_error_behaviour(rt):
     assert g.add_mesh(1, v, i, abi.material(textures={"base_color": (img, smp), "occlusion": (img, smp)})) == 0
 
 
+def test_degenerate_and_coincident_geometry(rt, oracle, blue_noise):
+    """Zero-area and collinear triangles never hit (det = 0 -> inf/NaN -> all comparisons false), exactly coincident
+    triangles resolve to the lowest global index, needle triangles and far-away / huge ones stay consistent with the
+    oracle's brute force — and a frame over such a scene is still bit-exact."""
+    desc = scenes.cornell_box()
+    v = scenes.make_vertices(np.array([[0, 1, 0], [0, 1, 0], [0, 1, 0],                 # a point
+                                       [-0.5, 0.5, 0.2], [0.0, 0.5, 0.2], [0.5, 0.5, 0.2],   # collinear
+                                       [-0.3, 0.8, 0.5], [0.3, 0.8, 0.5], [0.0, 1.3, 0.5],   # a real triangle ...
+                                       [-0.3, 0.8, 0.5], [0.3, 0.8, 0.5], [0.0, 1.3, 0.5],   # ... and its exact copy
+                                       [0.0, 0.2, 0.6], [1e-7, 0.2, 0.6], [0.0, 1.5, 0.6],   # needle
+                                       [-4e5, -1, -4e5], [4e5, -1, -4e5], [0, -1, 5e5]], dtype=np.float32),   # huge ground triangle
+                             np.tile(np.array([[0, 0, 1]], dtype=np.float32), (18, 1)))
+    desc.meshes.append(scenes.MeshDesc(50, v, np.arange(18, dtype=np.uint32), abi.material(base_color=(0.3, 0.7, 0.3, 1.0), roughness=0.6)))
+    desc.instances.append((50, [abi.IDENTITY_TRANSFORM.copy(), scenes.translate(0.0, 0.0, -0.2)]))
+    osc = oracle.OracleScene().load(desc)
+    osc.set_brute_force(True)
+    gsc = rt.Scene(0).load(desc)
+    rays = np.concatenate([camera_rays(oracle, desc, 200, 200), random_rays(20000, 91),
+                           make_rays([(0.0, 1.0, 2.0)] * 3, [(0, 0, -1), (0.0, 0.05, -1.0), (1e-4, 0.0, -1.0)])])
+    rays_t = rt.rays_to_device(rays)
+    hits = rt.hits_from_device(gsc.trace_closest(rays_t, len(rays)))
+    want = osc.trace_closest(rays)
+    assert_bits_equal(want, hits, "SrHit with degenerate / coincident triangles")
+    # the coincident pair: hits report the first copy (lower global index) of instance 0, never the second
+    n_before = sum(len(m.indices) // 3 * len(x) for m, (k, x) in zip(desc.meshes[:-1], desc.instances[:-1]))
+    tri_hit = hits["tri"][hits["tri"] != 0xFFFFFFFF]
+    assert (tri_hit == n_before + 2).any() and not (tri_hit == n_before + 3).any()
+    assert not np.isin(tri_hit, [n_before + 0, n_before + 1]).any()          # point and collinear triangles are never hit
+    assert np.array_equal(osc.trace_any(rays), gsc.trace_any(rays_t, len(rays)).cpu().numpy().view(np.uint32))
+    osc.set_brute_force(False)
+    run_both(rt, oracle, desc, 96, 96, 2, blue_noise)
+
+
 # ---- the two passes -----------------------------------------------------------------------------
 @pytest.mark.parametrize("name", list(make_golden.CASES))
 def test_passes_match_committed_golden(rt, name, blue_noise):
@@ -639,6 +672,23 @@ def test_device_lbvh_fast_build(rt, oracle, blue_noise, scene_fn, box):
     assert_bits_equal(osc.trace_closest(rays), rt.hits_from_device(gsc.trace_closest(rays_t, len(rays))), "SrHit (LBVH + update)")
     nodes, tris = gsc.read_bvh()
     _check_bvh(nodes, tris, st.max_depth, st.max_stack, stack_limit=47)
+
+
+def test_4k_frame_1m_triangles(rt, oracle, blue_noise):
+    """BASELINE.json config 5's extent (3840x2160) on the 1M-triangle scene: one full frame against the oracle, bit for
+    bit, plus the row-strip composition a tile-parallel run relies on (strip + halo launches == one full launch)."""
+    desc = scenes.heightfield(708)
+    W, H = 3840, 2160
+    osc, gsc, of, gf = run_both(rt, oracle, desc, W, H, 1, blue_noise)
+    full = gf.host()["raw_color"].copy()
+    assert np.isfinite(full).all() and full[:, :3].any()
+    from sunray_amd import distributed as sd
+    gf2 = rt.DeviceFrame(W, H, blue_noise)
+    m = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H)
+    cfg = abi.SrTraceConfig.reference()
+    for rank in range(4):
+        sd.render_strip(gsc, gf2, m, 0, cfg, 4, rank)
+    assert_bits_equal(full, gf2.host()["raw_color"], "4 strips (+halo) compose to the 4K frame")
 
 
 def test_device_lbvh_1m_triangles(rt, oracle):
