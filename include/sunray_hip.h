@@ -331,7 +331,10 @@ int sr_scene_end_frame(SrScene* scene);
  * SR_OP_FAST_BUILD = device LBVH build, SR_OP_UPDATE = in-place update if the layout allows) instead of the
  * heuristic's choice. The heuristic state is still advanced with the op performed. */
 int sr_scene_force_next_op(SrScene* scene, uint32_t op);
-/* Debug read-back of the device tree: n_nodes x 16 dwords, n_triangles x 12 floats (either may be NULL). */
+/* Node layout of the quantised wide BVH this build uses (csrc/bvh_layout.h): children per node, dwords per node, first
+ * plane dword, first child dword. */
+int sr_bvh_layout(uint32_t* width, uint32_t* node_dwords, uint32_t* plane_offset, uint32_t* child_offset);
+/* Debug read-back of the device tree: n_nodes x node_dwords dwords, n_triangles x 12 floats (either may be NULL). */
 int sr_scene_read_bvh(const SrScene* scene, uint32_t* nodes_out, float* tris_out);
 
 /* ResourceManager::add_blas (resource_manager.rs:417-447): sr_scene_add_mesh with the local-space emissive

@@ -13,7 +13,7 @@ _lib = None
 SYMBOLS = [
     "sr_last_error", "sr_version", "sr_camera_matrices", "sr_material_new", "sr_emissive_triangles_from_mesh",
     "sr_trace_config_default", "sr_scene_create", "sr_scene_destroy", "sr_as_state_initial", "sr_as_state_next_op", "sr_as_state_mark_built", "sr_scene_as_state", "sr_scene_end_frame",
-    "sr_scene_read_bvh", "sr_scene_force_next_op", "sr_scene_add_mesh", "sr_scene_add_blas", "sr_scene_remove", "sr_scene_add_image", "sr_scene_add_sampler", "sr_scene_set_instances",
+    "sr_bvh_layout", "sr_scene_read_bvh", "sr_scene_force_next_op", "sr_scene_add_mesh", "sr_scene_add_blas", "sr_scene_remove", "sr_scene_add_image", "sr_scene_add_sampler", "sr_scene_set_instances",
     "sr_scene_get_tables", "sr_scene_bvh_stats", "sr_scene_resolve_triangle", "sr_host_bvh_build", "sr_host_bvh_get",
     "sr_host_bvh_destroy", "sr_trace_closest", "sr_trace_any", "sr_shade_closest_hit", "sr_trace_ris", "sr_trace_final", "sr_post_temporal", "sr_post_denoise", "sr_post_tonemap", "sr_renderer_create", "sr_renderer_destroy",
     "sr_renderer_resize", "sr_renderer_load_mesh", "sr_renderer_set_config", "sr_renderer_render", "sr_renderer_wait_frame",

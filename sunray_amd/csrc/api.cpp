@@ -14,6 +14,7 @@
 
 #include "host.h"
 #include "bvh_gpu.h"
+#include "bvh_layout.h"
 #include "kernels.h"
 
 namespace {
@@ -457,7 +458,7 @@ int fast_build(SrScene* s) {
     if ((rc = upload_instance_tables(s)) != SR_OK) return rc;
     if ((rc = s->d_mesh_infos.upload(s->mesh_infos.data(), s->mesh_infos.size() * sizeof(SrMeshInfo))) != SR_OK) return rc;
     const uint32_t node_cap = n / 2 + 1024;
-    if ((rc = s->d_nodes.reserve((size_t)node_cap * 64)) != SR_OK || (rc = s->d_node_box.reserve((size_t)node_cap * 24)) != SR_OK ||
+    if ((rc = s->d_nodes.reserve((size_t)node_cap * srl::kNodeBytes)) != SR_OK || (rc = s->d_node_box.reserve((size_t)node_cap * 24)) != SR_OK ||
         (rc = s->d_tris.reserve((size_t)n * 48)) != SR_OK || (rc = s->d_shade.reserve((size_t)n * 48)) != SR_OK ||
         (rc = s->d_slot_of_gid.reserve((size_t)n * 4)) != SR_OK) return rc;
     if (any_textured) { if ((rc = s->d_shade_tex.reserve((size_t)n * 96)) != SR_OK) return rc; }
@@ -494,7 +495,7 @@ int fast_build(SrScene* s) {
     s->dev.n_tris = n;
     s->stats.n_triangles = n;
     s->stats.n_nodes = r.n_nodes;
-    s->stats.node_bytes = (uint64_t)r.n_nodes * 64;
+    s->stats.node_bytes = (uint64_t)r.n_nodes * srl::kNodeBytes;
     s->stats.tri_bytes = (uint64_t)n * 48;
     s->stats.max_depth = r.max_depth;
     s->stats.max_stack = r.max_stack;
@@ -574,11 +575,19 @@ void sr_as_state_initial(uint32_t build_type, SrAsState* out) { if (out) srh::as
 uint32_t sr_as_state_next_op(const SrAsState* state, int inputs_changed) { return state ? srh::as_state_next_op(*state, inputs_changed != 0) : SR_OP_NONE; }
 void sr_as_state_mark_built(SrAsState* state, uint32_t completed_op) { if (state) srh::as_state_mark_built(*state, completed_op); }
 
+int sr_bvh_layout(uint32_t* width, uint32_t* node_dwords, uint32_t* plane_offset, uint32_t* child_offset) {
+    if (width) *width = (uint32_t)srl::kBvhWidth;
+    if (node_dwords) *node_dwords = (uint32_t)srl::kNodeDwords;
+    if (plane_offset) *plane_offset = (uint32_t)srl::kPlaneOffset;
+    if (child_offset) *child_offset = (uint32_t)srl::kChildOffset;
+    return SR_OK;
+}
+
 int sr_scene_read_bvh(const SrScene* s, uint32_t* nodes_out, float* tris_out) {
     if (!s || !s->built) return fail(SR_ERR_STATE, "sr_scene_read_bvh: scene not built");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipDeviceSynchronize());
-    if (nodes_out) HIP_TRY(hipMemcpy(nodes_out, s->d_nodes.p, (size_t)s->stats.n_nodes * 64, hipMemcpyDeviceToHost));
+    if (nodes_out) HIP_TRY(hipMemcpy(nodes_out, s->d_nodes.p, (size_t)s->stats.n_nodes * srl::kNodeBytes, hipMemcpyDeviceToHost));
     if (tris_out && s->fid.n_triangles) HIP_TRY(hipMemcpy(tris_out, s->d_tris.p, (size_t)s->fid.n_triangles * 48, hipMemcpyDeviceToHost));
     return SR_OK;
 }
@@ -654,7 +663,7 @@ int full_build(SrScene* s) {
     s->dev.n_tris = s->fid.n_triangles;
     s->stats.n_triangles = s->fid.n_triangles;
     s->stats.n_nodes = bvh.n_nodes;
-    s->stats.node_bytes = (uint64_t)bvh.n_nodes * 64;
+    s->stats.node_bytes = (uint64_t)bvh.n_nodes * srl::kNodeBytes;
     s->stats.tri_bytes = (uint64_t)s->fid.n_triangles * 48;
     s->stats.max_depth = bvh.max_depth;
     s->stats.max_stack = bvh.max_stack;

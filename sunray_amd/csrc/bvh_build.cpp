@@ -14,6 +14,7 @@
 #include <cstring>
 #include <future>
 
+#include "bvh_layout.h"
 #include "host.h"
 
 namespace srh {
@@ -253,11 +254,12 @@ struct Collapser {
     // formed where the budget allows; the binary tree below always fits (height <= kMaxBinaryDepth).
     // Returns the worst-case number of entries actually needed.
     uint32_t emit(int node2, uint32_t depth, uint32_t budget, int* out_index) {
-        Child4 kids[4];
+        constexpr int W = srl::kBvhWidth;
+        Child4 kids[W];
         int nk = 0;
         kids[nk++] = child_of(&n2[(size_t)node2 * 16], 0);
         kids[nk++] = child_of(&n2[(size_t)node2 * 16], 1);
-        while (nk < 4) {
+        while (nk < W) {
             int best = -1; float best_area = -1.0f;
             for (int i = 0; i < nk; i++) if (kids[i].ref >= 0) { const float a = area_of(kids[i]); if (a > best_area) { best_area = a; best = i; } }
             if (best < 0) break;
@@ -269,9 +271,10 @@ struct Collapser {
             kids[best] = ca;
             kids[nk++] = cb;
         }
-        bool real[4] = {false, false, false, false};
+        bool real[W];
         int n_real = 0;
         float lo_n[3] = {INFINITY, INFINITY, INFINITY}, hi_n[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = 0; i < W; i++) real[i] = false;
         for (int i = 0; i < nk; i++) {
             const bool empty_leaf = kids[i].ref < 0 && ((~(uint32_t)kids[i].ref) & 7u) == 0u;
             real[i] = !empty_leaf;
@@ -280,10 +283,11 @@ struct Collapser {
             for (int a = 0; a < 3; a++) { lo_n[a] = std::min(lo_n[a], kids[i].lo[a]); hi_n[a] = std::max(hi_n[a], kids[i].hi[a]); }
         }
         const size_t self = out.size();
-        *out_index = (int)(self / 16);
-        out.resize(self + 16, 0u);
+        *out_index = (int)(self / srl::kNodeDwords);
+        out.resize(self + srl::kNodeDwords, 0u);
         max_depth = std::max(max_depth, depth);
-        uint32_t plane[6] = {0, 0, 0, 0, 0, 0};   // LX LY LZ HX HY HZ
+        uint32_t plane[6 * srl::kPlaneDwords];   // LX LY LZ HX HY HZ, kPlaneDwords dwords each
+        for (auto& v : plane) v = 0u;
         uint32_t exps = 0;
         float origin[3] = {0.0f, 0.0f, 0.0f};
         if (n_real > 0) {
@@ -307,7 +311,7 @@ struct Collapser {
                 }
                 const float scale = std::ldexp(1.0f, e);
                 exps |= (uint32_t)(e + 127) << (8 * a);
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < W; i++) {
                     uint32_t ql = 255u, qh = 0u;   // inverted box for unused children
                     if (i < nk && real[i]) {
                         int l = (int)std::floor(((double)kids[i].lo[a] - (double)origin[a]) / (double)scale - kGuardCells);
@@ -318,16 +322,19 @@ struct Collapser {
                         while (fmaf((float)h, scale, origin[a]) < kids[i].hi[a]) h++;
                         ql = (uint32_t)l; qh = (uint32_t)h;
                     }
-                    plane[a] |= ql << (8 * i);
-                    plane[3 + a] |= qh << (8 * i);
+                    plane[a * srl::kPlaneDwords + i / 4] |= ql << (8 * (i % 4));
+                    plane[(3 + a) * srl::kPlaneDwords + i / 4] |= qh << (8 * (i % 4));
                 }
             }
         } else {
-            for (int a = 0; a < 3; a++) { plane[a] = 0xFFFFFFFFu; plane[3 + a] = 0u; exps |= 127u << (8 * a); }
+            for (int a = 0; a < 3; a++) {
+                for (int d = 0; d < srl::kPlaneDwords; d++) { plane[a * srl::kPlaneDwords + d] = 0xFFFFFFFFu; plane[(3 + a) * srl::kPlaneDwords + d] = 0u; }
+                exps |= 127u << (8 * a);
+            }
         }
         uint32_t below = 0;
-        int refs[4];
-        for (int i = 0; i < 4; i++) {
+        int refs[W];
+        for (int i = 0; i < W; i++) {
             refs[i] = Builder::leaf_ref(0, 0);
             if (i < nk && real[i]) {
                 if (kids[i].ref >= 0) {
@@ -339,9 +346,8 @@ struct Collapser {
         }
         uint32_t* q = &out[self];
         memcpy(q + 0, origin, 12); q[3] = exps;
-        q[4] = plane[0]; q[5] = plane[1]; q[6] = plane[2]; q[7] = plane[3];
-        q[8] = plane[4]; q[9] = plane[5]; q[10] = 0u; q[11] = 0u;
-        memcpy(q + 12, refs, 16);
+        memcpy(q + srl::kPlaneOffset, plane, sizeof(plane));
+        memcpy(q + srl::kChildOffset, refs, sizeof(refs));
         return below + (uint32_t)std::max(n_real - 1, 0);
     }
 };
@@ -355,7 +361,7 @@ static void collapse_to_bvh4(BvhResult& res, uint32_t stack_budget) {
     int root = 0;
     res.max_stack = c.emit(0, 1, stack_budget, &root);
     res.max_depth = c.max_depth;
-    res.n_nodes = (uint32_t)(res.nodes.size() / 16);
+    res.n_nodes = (uint32_t)(res.nodes.size() / srl::kNodeDwords);
 }
 
 void flatten_instances(const std::vector<HostMesh>& meshes, const FrameInstanceData& fid, std::vector<BuildTri>& out) {
@@ -426,7 +432,11 @@ void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult&
     }
     res.nodes2.swap(top.nodes);
     res.sah_cost = (float)top.cost;
+#ifdef SR_STACK_BUDGET
+    collapse_to_bvh4(res, (uint32_t)SR_STACK_BUDGET);   // experiment: a stack budget above the binary depth bound
+#else
     collapse_to_bvh4(res, max_depth);
+#endif
     res.order = b.order;
     res.tris.resize((size_t)n * 12);
     for (uint32_t i = 0; i < n; i++) {

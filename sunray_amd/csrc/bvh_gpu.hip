@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "bvh_gpu.h"
+#include "bvh_layout.h"
 
 namespace srd {
 
@@ -69,16 +70,17 @@ __device__ __forceinline__ void tri_box(const float4* tris, uint32_t slot, float
 constexpr double kGuardCells = 1.0 / 32.0;   // guard band around every quantised plane (see bvh_build.cpp, traverse.h)
 
 __global__ void refit_level_kernel(uint32_t* nodes, const float4* tris, float* node_box, const uint32_t* level_nodes, uint32_t first, uint32_t count) {
+    constexpr int W = srl::kBvhWidth;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint32_t node = level_nodes ? level_nodes[first + i] : first + i;   // null list: the level is the index range itself
-    uint32_t* q = nodes + (size_t)node * 16;
-    float lo[4][3], hi[4][3];
-    bool real[4];
+    uint32_t* q = nodes + (size_t)node * srl::kNodeDwords;
+    float lo[W][3], hi[W][3];
+    bool real[W];
     float lo_n[3] = {INFINITY, INFINITY, INFINITY}, hi_n[3] = {-INFINITY, -INFINITY, -INFINITY};
     int n_real = 0;
-    for (int c = 0; c < 4; c++) {
-        const int ref = (int)q[12 + c];
+    for (int c = 0; c < W; c++) {
+        const int ref = (int)q[srl::kChildOffset + c];
         for (int a = 0; a < 3; a++) { lo[c][a] = INFINITY; hi[c][a] = -INFINITY; }
         real[c] = false;
         if (ref >= 0) {
@@ -94,7 +96,8 @@ __global__ void refit_level_kernel(uint32_t* nodes, const float4* tris, float* n
         n_real++;
         for (int a = 0; a < 3; a++) { lo_n[a] = fminf(lo_n[a], lo[c][a]); hi_n[a] = fmaxf(hi_n[a], hi[c][a]); }
     }
-    uint32_t plane[6] = {0, 0, 0, 0, 0, 0}, exps = 0;
+    uint32_t plane[6 * srl::kPlaneDwords], exps = 0;
+    for (int k = 0; k < 6 * srl::kPlaneDwords; k++) plane[k] = 0u;
     float origin[3] = {0.0f, 0.0f, 0.0f};
     if (n_real > 0) {
         for (int a = 0; a < 3; a++) {
@@ -106,7 +109,7 @@ __global__ void refit_level_kernel(uint32_t* nodes, const float4* tris, float* n
             for (; e < 127; e++) {   // grow the grid until every child's upper plane fits in a byte
                 const float scale = ldexpf(1.0f, e);
                 bool ok = true;
-                for (int c = 0; c < 4 && ok; c++) {
+                for (int c = 0; c < W && ok; c++) {
                     if (!real[c]) continue;
                     int qh = (int)ceil(((double)hi[c][a] - (double)origin[a]) / (double)scale + kGuardCells);
                     qh = max(qh, 0);
@@ -117,7 +120,7 @@ __global__ void refit_level_kernel(uint32_t* nodes, const float4* tris, float* n
             }
             const float scale = ldexpf(1.0f, e);
             exps |= (uint32_t)(e + 127) << (8 * a);
-            for (int c = 0; c < 4; c++) {
+            for (int c = 0; c < W; c++) {
                 uint32_t ql = 255u, qh = 0u;   // inverted box for unused children
                 if (real[c]) {
                     int l = (int)floor(((double)lo[c][a] - (double)origin[a]) / (double)scale - kGuardCells);
@@ -128,16 +131,18 @@ __global__ void refit_level_kernel(uint32_t* nodes, const float4* tris, float* n
                     while (h < 255 && fmaf((float)h, scale, origin[a]) < hi[c][a]) h++;
                     ql = (uint32_t)l; qh = (uint32_t)h;
                 }
-                plane[a] |= ql << (8 * c);
-                plane[3 + a] |= qh << (8 * c);
+                plane[a * srl::kPlaneDwords + c / 4] |= ql << (8 * (c % 4));
+                plane[(3 + a) * srl::kPlaneDwords + c / 4] |= qh << (8 * (c % 4));
             }
         }
     } else {
-        for (int a = 0; a < 3; a++) { plane[a] = 0xFFFFFFFFu; plane[3 + a] = 0u; exps |= 127u << (8 * a); }
+        for (int a = 0; a < 3; a++) {
+            for (int d = 0; d < srl::kPlaneDwords; d++) { plane[a * srl::kPlaneDwords + d] = 0xFFFFFFFFu; plane[(3 + a) * srl::kPlaneDwords + d] = 0u; }
+            exps |= 127u << (8 * a);
+        }
     }
     q[0] = __float_as_uint(origin[0]); q[1] = __float_as_uint(origin[1]); q[2] = __float_as_uint(origin[2]); q[3] = exps;
-    q[4] = plane[0]; q[5] = plane[1]; q[6] = plane[2]; q[7] = plane[3];
-    q[8] = plane[4]; q[9] = plane[5];
+    for (int k = 0; k < 6 * srl::kPlaneDwords; k++) q[srl::kPlaneOffset + k] = plane[k];
     float* b = node_box + (size_t)node * 6;
     for (int a = 0; a < 3; a++) { b[a] = lo_n[a]; b[3 + a] = hi_n[a]; }
 }
@@ -305,12 +310,13 @@ __global__ void lbvh_collapse_kernel(uint32_t* nodes, uint32_t level_first, uint
     const uint32_t self = level_first + t;
     const int bin = bin_of_node[self];
     const uint32_t budget = budget_of_node[self];
-    LbvhKid kids[4];
+    constexpr int W = srl::kBvhWidth;
+    LbvhKid kids[W];
     int nk = 0;
     const int2 ch = children[bin];
     kids[nk++] = lbvh_kid(ch.x, range, bin_box, bin_height);
     kids[nk++] = lbvh_kid(ch.y, range, bin_box, bin_height);
-    while (nk < 4) {
+    while (nk < W) {
         int best = -1; float best_area = -1.0f;
         for (int i = 0; i < nk; i++) if (kids[i].bin >= 0 && kids[i].area > best_area) { best_area = kids[i].area; best = i; }
         if (best < 0) break;
@@ -322,11 +328,11 @@ __global__ void lbvh_collapse_kernel(uint32_t* nodes, uint32_t level_first, uint
         kids[best] = ka;
         kids[nk++] = kb;
     }
-    uint32_t* q = nodes + (size_t)self * 16;
-    for (int k = 0; k < 12; k++) q[k] = 0u;
+    uint32_t* q = nodes + (size_t)self * srl::kNodeDwords;
+    for (int k = 0; k < srl::kNodeDwords; k++) q[k] = 0u;
     const uint32_t mine = prefix_of_node[self] + (uint32_t)(nk - 1);
     atomicMax(counters + 1, mine);
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < W; i++) {
         uint32_t ref = 0xFFFFFFFFu;                              // leaf_ref(0, 0): unused child
         if (i < nk) {
             if (kids[i].bin >= 0) {
@@ -339,7 +345,7 @@ __global__ void lbvh_collapse_kernel(uint32_t* nodes, uint32_t level_first, uint
                 } else { atomicExch(counters + 2, 1u); }
             } else ref = ~((kids[i].first << 3) | kids[i].count);
         }
-        q[12 + i] = ref;
+        q[srl::kChildOffset + i] = ref;
     }
 }
 

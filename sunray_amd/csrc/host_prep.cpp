@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "bvh_layout.h"
 #include "host.h"
 
 namespace srh {
@@ -252,14 +253,14 @@ void as_state_mark_built(SrAsState& s, uint32_t completed) {                   /
 }
 
 void tree_levels(const std::vector<uint32_t>& nodes, std::vector<uint32_t>& level_nodes, std::vector<uint32_t>& level_offsets) {
-    const uint32_t n = (uint32_t)(nodes.size() / 16);
+    const uint32_t n = (uint32_t)(nodes.size() / srl::kNodeDwords);
     std::vector<std::vector<uint32_t>> levels;
     std::vector<uint32_t> cur{0u}, next;
     while (!cur.empty() && n) {
         levels.push_back(cur);
         next.clear();
         for (uint32_t node : cur)
-            for (int c = 0; c < 4; c++) { const int ref = (int)nodes[(size_t)node * 16 + 12 + c]; if (ref >= 0) next.push_back((uint32_t)ref); }
+            for (int c = 0; c < srl::kBvhWidth; c++) { const int ref = (int)nodes[(size_t)node * srl::kNodeDwords + srl::kChildOffset + c]; if (ref >= 0) next.push_back((uint32_t)ref); }
         cur.swap(next);
     }
     level_nodes.clear(); level_offsets.assign(1, 0u);

@@ -19,12 +19,16 @@
 // One lane = one ray. The per-lane traversal stack lives in LDS, interleaved as stack[level][lane]
 // so a wave's pushes/pops hit 64 consecutive banks (conflict-free ds_write_b32 / ds_read_b32).
 #pragma once
+#include "bvh_layout.h"
 #include "rt_device.h"
 
 namespace srd {
 
+#ifdef SR_STACK_BUDGET
+constexpr int kStackMax = SR_STACK_BUDGET;   // experiment hook (wider trees need a deeper stack)
+#else
 constexpr int kStackMax = 31;         // stack entries per lane the builders shape a tree for (= kMaxBinaryDepth); with the
-                                      // spare level of the branch-free push that is 32 LDS levels = 32 KB per workgroup.
+#endif                                // spare level of the branch-free push that is 32 LDS levels (8 KB per wave).
                                       // Launches size the dynamic LDS stack to what the scene's tree actually needs.
 constexpr int kMaxBinaryDepth = 31;  // depth bound of the binary tree the 4-wide tree is collapsed from
 constexpr int kSentinel = 0x7fffffff;
@@ -183,6 +187,61 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
     int sp = 0;
     int node = 0;  // the root is always inner node 0
     while (node != kSentinel) {
+#if SR_BVH_WIDTH == 8
+        while (node >= 0 && node != kSentinel) {   // while-while: an if-if loop (one node of either kind per iteration) measured 5 % slower
+            const float4* n = nodes + (size_t)node * (srl::kNodeDwords / 4);
+            const float4 h0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], qa = n[4], qb = n[5];
+            const int4 ca = make_int4(__float_as_int(qa.x), __float_as_int(qa.y), __float_as_int(qa.z), __float_as_int(qa.w));
+            const int4 cb = make_int4(__float_as_int(qb.x), __float_as_int(qb.y), __float_as_int(qb.z), __float_as_int(qb.w));
+            if (STATS) st.boxes += 8;
+            const uint32_t ex = __float_as_uint(h0.w);
+            // planes: LX(2 dwords) LY(2) | LZ(2) HX(2) | HY(2) HZ(2); dword 0 of a plane = children 0..3, dword 1 = children 4..7
+            const uint32_t LX0 = __float_as_uint(q1.x), LX1 = __float_as_uint(q1.y), LY0 = __float_as_uint(q1.z), LY1 = __float_as_uint(q1.w);
+            const uint32_t LZ0 = __float_as_uint(q2.x), LZ1 = __float_as_uint(q2.y), HX0 = __float_as_uint(q2.z), HX1 = __float_as_uint(q2.w);
+            const uint32_t HY0 = __float_as_uint(q3.x), HY1 = __float_as_uint(q3.y), HZ0 = __float_as_uint(q3.z), HZ1 = __float_as_uint(q3.w);
+            NodePlanes p, r;      // p: children 0..3, r: children 4..7
+            p.nx = rs.sx ? HX0 : LX0; p.fx = rs.sx ? LX0 : HX0; r.nx = rs.sx ? HX1 : LX1; r.fx = rs.sx ? LX1 : HX1;
+            p.ny = rs.sy ? HY0 : LY0; p.fy = rs.sy ? LY0 : HY0; r.ny = rs.sy ? HY1 : LY1; r.fy = rs.sy ? LY1 : HY1;
+            p.nz = rs.sz ? HZ0 : LZ0; p.fz = rs.sz ? LZ0 : HZ0; r.nz = rs.sz ? HZ1 : LZ1; r.fz = rs.sz ? LZ1 : HZ1;
+            p.ax = __uint_as_float((ex & 0xFFu) << 23) * rs.inv.x; p.ay = __uint_as_float(((ex >> 8) & 0xFFu) << 23) * rs.inv.y;
+            p.az = __uint_as_float(((ex >> 16) & 0xFFu) << 23) * rs.inv.z;
+            p.bx = (h0.x - rs.o.x) * rs.inv.x; p.by = (h0.y - rs.o.y) * rs.inv.y; p.bz = (h0.z - rs.o.z) * rs.inv.z;
+            r.ax = p.ax; r.ay = p.ay; r.az = p.az; r.bx = p.bx; r.by = p.by; r.bz = p.bz;
+            float n0, n1, n2, n3, n4, n5, n6, n7;
+            const bool b0 = child_hit<0>(p, t_lo, cull, n0), b1 = child_hit<1>(p, t_lo, cull, n1);
+            const bool b2 = child_hit<2>(p, t_lo, cull, n2), b3 = child_hit<3>(p, t_lo, cull, n3);
+            const bool b4 = child_hit<0>(r, t_lo, cull, n4), b5 = child_hit<1>(r, t_lo, cull, n5);
+            const bool b6 = child_hit<2>(r, t_lo, cull, n6), b7 = child_hit<3>(r, t_lo, cull, n7);
+            // nearest hit child first (any-hit: any hit child), the other hit children pushed unordered and branch-free;
+            // key = entry distance with the low 3 mantissa bits replaced by the child slot
+            uint32_t k0, k1, k2, k3, k4, k5, k6, k7;
+            if (ANY) {
+                k0 = b0 ? 0u : 0xFFFFFFFFu; k1 = b1 ? 1u : 0xFFFFFFFFu; k2 = b2 ? 2u : 0xFFFFFFFFu; k3 = b3 ? 3u : 0xFFFFFFFFu;
+                k4 = b4 ? 4u : 0xFFFFFFFFu; k5 = b5 ? 5u : 0xFFFFFFFFu; k6 = b6 ? 6u : 0xFFFFFFFFu; k7 = b7 ? 7u : 0xFFFFFFFFu;
+            } else {
+                k0 = b0 ? ((__float_as_uint(fmaxf(n0, 0.0f)) & ~7u) | 0u) : 0xFFFFFFFFu;
+                k1 = b1 ? ((__float_as_uint(fmaxf(n1, 0.0f)) & ~7u) | 1u) : 0xFFFFFFFFu;
+                k2 = b2 ? ((__float_as_uint(fmaxf(n2, 0.0f)) & ~7u) | 2u) : 0xFFFFFFFFu;
+                k3 = b3 ? ((__float_as_uint(fmaxf(n3, 0.0f)) & ~7u) | 3u) : 0xFFFFFFFFu;
+                k4 = b4 ? ((__float_as_uint(fmaxf(n4, 0.0f)) & ~7u) | 4u) : 0xFFFFFFFFu;
+                k5 = b5 ? ((__float_as_uint(fmaxf(n5, 0.0f)) & ~7u) | 5u) : 0xFFFFFFFFu;
+                k6 = b6 ? ((__float_as_uint(fmaxf(n6, 0.0f)) & ~7u) | 6u) : 0xFFFFFFFFu;
+                k7 = b7 ? ((__float_as_uint(fmaxf(n7, 0.0f)) & ~7u) | 7u) : 0xFFFFFFFFu;
+            }
+            const uint32_t kmin = min(min(min(k0, k1), min(k2, k3)), min(min(k4, k5), min(k6, k7)));
+            const uint32_t slot = kmin & 7u;
+            stack_base[sp * stride] = ca.x; sp += (b0 && k0 != kmin) ? 1 : 0;
+            stack_base[sp * stride] = ca.y; sp += (b1 && k1 != kmin) ? 1 : 0;
+            stack_base[sp * stride] = ca.z; sp += (b2 && k2 != kmin) ? 1 : 0;
+            stack_base[sp * stride] = ca.w; sp += (b3 && k3 != kmin) ? 1 : 0;
+            stack_base[sp * stride] = cb.x; sp += (b4 && k4 != kmin) ? 1 : 0;
+            stack_base[sp * stride] = cb.y; sp += (b5 && k5 != kmin) ? 1 : 0;
+            stack_base[sp * stride] = cb.z; sp += (b6 && k6 != kmin) ? 1 : 0;
+            stack_base[sp * stride] = cb.w; sp += (b7 && k7 != kmin) ? 1 : 0;
+            const int lo4 = pick(ca, slot), hi4 = pick(cb, slot);
+            node = (kmin != 0xFFFFFFFFu) ? ((slot & 4u) ? hi4 : lo4) : SR_POP();
+        }
+#else
         while (node >= 0 && node != kSentinel) {   // while-while: an if-if loop (one node of either kind per iteration) measured 5 % slower
             const float4* n = nodes + (size_t)node * 4;
             const float4 h0 = n[0], q1 = n[1], q2 = n[2], qc = n[3];
@@ -227,6 +286,7 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
             stack_base[sp * stride] = child.w; sp += (b3 && k3 != kmin) ? 1 : 0;
             node = (kmin != 0xFFFFFFFFu) ? pick(child, slot) : SR_POP();
         }
+#endif
         if (node == kSentinel) break;
         // leaf
         const uint32_t lv = ~(uint32_t)node;

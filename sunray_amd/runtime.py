@@ -47,8 +47,15 @@ def emissive_triangles_from_mesh(vertices, indices, material):
     return out[: n.value].copy()
 
 
+def bvh_layout():
+    """(children per node, dwords per node, first plane dword, first child dword) of this build's BVH (csrc/bvh_layout.h)."""
+    w, nd, po, co = (C.c_uint32() for _ in range(4))
+    check(lib().sr_bvh_layout(C.byref(w), C.byref(nd), C.byref(po), C.byref(co)))
+    return w.value, nd.value, po.value, co.value
+
+
 def host_bvh(v0_e1_e2):
-    """Host-only BVH build (no GPU): returns (nodes[n,16] u32, tris[n,12] f32, max_depth, max_stack)."""
+    """Host-only BVH build (no GPU): returns (nodes[n, node_dwords] u32, tris[n,12] f32, max_depth, max_stack)."""
     v = np.ascontiguousarray(v0_e1_e2, dtype=np.float32).reshape(-1, 9)
     h = C.c_void_p()
     check(lib().sr_host_bvh_build(_p(v), C.c_uint32(len(v)), C.byref(h)))
@@ -56,31 +63,32 @@ def host_bvh(v0_e1_e2):
         np_, tp = C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()
         nn, nt, md, ms = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(lib().sr_host_bvh_get(h, C.byref(np_), C.byref(nn), C.byref(tp), C.byref(nt), C.byref(md), C.byref(ms)))
-        nodes = np.ctypeslib.as_array(np_, shape=(nn.value, 16)).copy()
+        nodes = np.ctypeslib.as_array(np_, shape=(nn.value, bvh_layout()[1])).copy()
         tris = np.ctypeslib.as_array(tp, shape=(nt.value, 12)).copy() if nt.value else np.zeros((0, 12), np.float32)
     finally:
         lib().sr_host_bvh_destroy(h)
     return nodes, tris, md.value, ms.value
 
 
-def decode_node(node16):
-    """Child boxes of one 64-byte quantised node as the kernel decodes them: plane = fmaf(q, 2^e, origin).
-    Returns (lo[4,3], hi[4,3], child[4]) in float32 / int32."""
-    n = np.asarray(node16, dtype=np.uint32)
+def decode_node(node):
+    """Child boxes of one quantised node as the kernel decodes them: plane = fmaf(q, 2^e, origin).
+    Returns (lo[W,3], hi[W,3], child[W]) in float32 / int32."""
+    W, _, po, co = bvh_layout()
+    n = np.asarray(node, dtype=np.uint32)
     origin = n[0:3].view(np.float32)
     ex = int(n[3])
     scale = np.array([np.uint32(((ex >> (8 * a)) & 0xFF) << 23) for a in range(3)], dtype=np.uint32).view(np.float32)
-    planes = n[4:10]  # LX LY LZ HX HY HZ
-    lo = np.zeros((4, 3), np.float32)
-    hi = np.zeros((4, 3), np.float32)
-    for c in range(4):
+    pd = W // 4                      # dwords per plane; planes LX LY LZ HX HY HZ
+    lo = np.zeros((W, 3), np.float32)
+    hi = np.zeros((W, 3), np.float32)
+    for c in range(W):
         for a in range(3):
-            ql = np.float32((int(planes[a]) >> (8 * c)) & 0xFF)
-            qh = np.float32((int(planes[3 + a]) >> (8 * c)) & 0xFF)
+            ql = np.float32((int(n[po + a * pd + c // 4]) >> (8 * (c % 4))) & 0xFF)
+            qh = np.float32((int(n[po + (3 + a) * pd + c // 4]) >> (8 * (c % 4))) & 0xFF)
             # one rounding, like v_fma_f32: the product q * 2^e is exact in float64
             lo[c, a] = np.float32(np.float64(ql) * np.float64(scale[a]) + np.float64(origin[a]))
             hi[c, a] = np.float32(np.float64(qh) * np.float64(scale[a]) + np.float64(origin[a]))
-    return lo, hi, n[12:16].view(np.int32)
+    return lo, hi, n[co:co + W].view(np.int32)
 
 
 class DeviceFrame:
@@ -211,7 +219,7 @@ class Scene:
 
     def read_bvh(self):
         st = self.bvh_stats()
-        nodes = np.zeros((st.n_nodes, 16), dtype=np.uint32)
+        nodes = np.zeros((st.n_nodes, bvh_layout()[1]), dtype=np.uint32)
         tris = np.zeros((max(st.n_triangles, 1), 12), dtype=np.float32)
         check(lib().sr_scene_read_bvh(self._h, _p(nodes), _p(tris)))
         return nodes, tris[:st.n_triangles]

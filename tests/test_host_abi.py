@@ -91,7 +91,8 @@ def _world_tris(desc):
 
 
 def _check_bvh(nodes, tris, max_depth, max_stack, stack_limit=31):
-    """Walks the 64-byte quantised 4-wide nodes exactly as the kernel decodes them (traverse.h)."""
+    """Walks the quantised wide nodes exactly as the kernel decodes them (traverse.h, bvh_layout.h)."""
+    W = rt.bvh_layout()[0]
     n = len(tris)
     seen = np.zeros(n, dtype=int)
     depth_seen = [0]
@@ -102,7 +103,7 @@ def _check_bvh(nodes, tris, max_depth, max_stack, stack_limit=31):
         lo4, hi4, ch = rt.decode_node(nodes[node])
         lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
         stack_below, n_real = 0, 0
-        for c in range(4):
+        for c in range(W):
             lo, hi = lo4[c], hi4[c]
             if ch[c] >= 0:
                 assert ch[c] > node  # children always follow their parent (depth-first on the host, breadth-first on the device)
