@@ -570,6 +570,43 @@ def test_renderer_load_gltf_unload_reload(rt, oracle, tmp_path):
     r.close()
 
 
+def test_png_example_end_to_end(rt, tmp_path):
+    """examples/png.py (the reference's examples/png): glTF in, PNG out; the PNG decodes back to the renderer's bytes."""
+    import subprocess
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import gltf_util
+    from oracle import gltf_ref
+    desc = small_atrium()
+    glb, png = str(tmp_path / "a.glb"), str(tmp_path / "a.png")
+    gltf_util.scene_to_gltf(desc, glb)
+    cam = ",".join(str(v) for v in (*desc.camera_pos, *desc.camera_target, desc.fov_y))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, os.path.join(root, "examples", "png.py"), glb, png, "--size", "160x96", "--camera", cam])
+    img = gltf_ref.decode_png(open(png, "rb").read())
+    r = rt.Renderer((160, 96))
+    _, inst = r.load_gltf(glb)
+    want = r.render_to_host_memory((desc.camera_pos, desc.camera_target, desc.fov_y), inst)
+    assert img.shape == (96, 160, 4) and (img == want).all() and (img[..., 3] == 255).all() and img[..., :3].std() > 5
+
+
+def test_non_finite_rays_terminate_as_misses(rt, oracle):
+    """NaN / infinite origins, directions and intervals: every comparison of the triangle test is false -> miss, on both
+    sides, and the traversal terminates."""
+    desc = scenes.cornell_box()
+    osc, gsc = oracle.OracleScene().load(desc), rt.Scene(0).load(desc)
+    nan, inf = float("nan"), float("inf")
+    o = [(nan, 1, 2), (0, 1, 2), (inf, 1, 2), (0, 1, 2), (0, 1, 2), (0, 1, 2), (0, -inf, 2), (0, 1, 2)]
+    d = [(0, 0, -1), (nan, 0, -1), (0, 0, -1), (inf, 0, -1), (0, 0, 0), (0, 0, -1), (0, 0, -1), (0, 0, -1)]
+    rays = make_rays(o, d)
+    rays["tmin"][5] = nan
+    rays["tmax"][7] = nan
+    rays_t = rt.rays_to_device(rays)
+    hits = rt.hits_from_device(gsc.trace_closest(rays_t, len(rays)))
+    assert_bits_equal(osc.trace_closest(rays), hits, "non-finite rays")
+    assert (hits["tri"] == 0xFFFFFFFF).all() and (hits["t"] == -1.0).all()
+    assert np.array_equal(osc.trace_any(rays), gsc.trace_any(rays_t, len(rays)).cpu().numpy().view(np.uint32))
+
+
 # ---- acceleration-structure maintenance (SURVEY §8f #2) -------------------------------------------
 def _moving_instances(desc, f):
     """Every instance orbits / spins / breathes a little differently each frame; scales stay non-uniform."""
