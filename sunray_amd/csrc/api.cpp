@@ -95,7 +95,6 @@ struct SrScene {
     std::vector<uint32_t> shape;            // mesh slot of every instance of the built tree: an UPDATE needs the same layout
     SrAsState as_state{0, 0, 0, 0};         // SometimesChanges -> Optimal (resource_manager.rs:119-126, mod.rs:86-91)
     uint32_t last_op = SR_OP_NONE;
-    std::vector<uint64_t> last_keys; std::vector<uint32_t> last_counts; std::vector<SrTransform> last_transforms;
     srd::DevScene dev{};
     SrBvhStats stats{};
     bool built = false;
@@ -520,10 +519,6 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     s->fid = std::move(fid);
     s->emissive_table = s->emissive_tris;
     if (s->emissive_table.empty()) { SrEmissiveTriangle z; memset(&z, 0, sizeof(z)); s->emissive_table.push_back(z); }
-    uint32_t n_xf = 0;
-    for (uint32_t k = 0; k < n_keys; k++) n_xf += counts[k];
-    s->last_keys.assign(keys, keys + n_keys); s->last_counts.assign(counts, counts + n_keys);
-    s->last_transforms.assign(transforms, transforms + n_xf);
     // Tlas::queue_build (tlas.rs:155-191): the instance data is new, so the heuristic is asked with inputs_changed =
     // true; an UPDATE needs the same instance layout (here: the same mesh per instance and unchanged meshes),
     // anything else is a rebuild. The very first build is the quality build (Tlas::new).
