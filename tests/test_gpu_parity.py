@@ -589,6 +589,16 @@ def test_png_example_end_to_end(rt, tmp_path):
     assert img.shape == (96, 160, 4) and (img == want).all() and (img[..., 3] == 255).all() and img[..., :3].std() > 5
 
 
+def test_randomised_soups_all_tree_kinds(rt, oracle):
+    """scripts/gpu_fuzz_trace.py in small: random triangle soups over five decades of scale, thin triangles, rotated and
+    non-uniformly scaled instances; axis-parallel rays, rays aimed at vertices and edge midpoints, rays starting on
+    geometry — against the oracle, for the host SAH tree, the device LBVH and an in-place update of it."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_fuzz_trace.py"), "3", "6"], capture_output=True, text=True)
+    assert out.returncode == 0 and "TOTAL mismatches 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_non_finite_rays_terminate_as_misses(rt, oracle):
     """NaN / infinite origins, directions and intervals: every comparison of the triangle test is false -> miss, on both
     sides, and the traversal terminates."""
