@@ -599,6 +599,16 @@ def test_randomised_soups_all_tree_kinds(rt, oracle):
     assert out.returncode == 0 and "TOTAL mismatches 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_randomised_materials_full_frames(rt, oracle):
+    """scripts/gpu_fuzz_passes.py in small: Cornell boxes filled with random spheres / patches of random materials (diffuse,
+    rough and smooth metal, glass of random ior, lights of random strength, textured with normal maps), four frames with a
+    moving camera; radiance, reservoirs, G-buffer and the tonemapped output against the oracle, bit for bit."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_fuzz_passes.py"), "5", "4"], capture_output=True, text=True)
+    assert out.returncode == 0 and "TOTAL differing bytes 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_non_finite_rays_terminate_as_misses(rt, oracle):
     """NaN / infinite origins, directions and intervals: every comparison of the triangle test is false -> miss, on both
     sides, and the traversal terminates."""
