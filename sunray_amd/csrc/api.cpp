@@ -246,10 +246,17 @@ int sr_scene_add_blas(SrScene* s, uint64_t key, const SrVertex* vertices, uint32
     m.indices.assign(indices, indices + n_indices);
     m.n_vertices = n_vertices; m.n_indices = n_indices;
     m.material = *material;
-    HIP_TRY(hipMalloc(&m.d_vertices, sizeof(SrVertex) * (size_t)n_vertices));
-    HIP_TRY(hipMemcpy(m.d_vertices, vertices, sizeof(SrVertex) * (size_t)n_vertices, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&m.d_indices, sizeof(uint32_t) * (size_t)n_indices));
-    HIP_TRY(hipMemcpy(m.d_indices, indices, sizeof(uint32_t) * (size_t)n_indices, hipMemcpyHostToDevice));
+    {
+        hipError_t e = hipMalloc(&m.d_vertices, sizeof(SrVertex) * (size_t)n_vertices);
+        if (e == hipSuccess) e = hipMemcpy(m.d_vertices, vertices, sizeof(SrVertex) * (size_t)n_vertices, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(&m.d_indices, sizeof(uint32_t) * (size_t)n_indices);
+        if (e == hipSuccess) e = hipMemcpy(m.d_indices, indices, sizeof(uint32_t) * (size_t)n_indices, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (m.d_vertices) (void)hipFree(m.d_vertices);
+            if (m.d_indices) (void)hipFree(m.d_indices);
+            return fail(e == hipErrorOutOfMemory ? SR_ERR_OOM : SR_ERR_HIP, std::string("load_mesh: geometry upload failed: ") + hipGetErrorString(e));
+        }
+    }
     for (uint32_t i = 0; i < n_emissive; i++) {
         uint32_t es;
         if (!s->free_emissive_slots.empty()) { es = s->free_emissive_slots.back(); s->free_emissive_slots.pop_back(); s->emissive_tris[es] = emissive[i]; }

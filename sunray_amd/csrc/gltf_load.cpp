@@ -36,7 +36,15 @@ struct Json {
     }
     bool has(const char* key) const { return get(key) != nullptr; }
     double number(const char* key, double dflt) const { const Json* j = get(key); return (j && j->kind == Num) ? j->num : dflt; }
-    long index(const char* key) const { const Json* j = get(key); return (j && j->kind == Num) ? (long)j->num : -1; }
+    long index(const char* key) const {      // non-negative integer below 2^31, else -1
+        const Json* j = get(key);
+        return (j && j->kind == Num && j->num >= 0.0 && j->num < 2147483648.0) ? (long)j->num : -1;
+    }
+    size_t size_value(const char* key) const {   // byte offsets / counts: clamped to [0, 2^48)
+        const Json* j = get(key);
+        if (!j || j->kind != Num || !(j->num >= 0.0)) return 0;
+        return j->num < 281474976710656.0 ? (size_t)j->num : (size_t)281474976710655ull;
+    }
     size_t size() const { return kind == Arr ? arr.size() : 0; }
 };
 
@@ -184,6 +192,7 @@ bool decode_png(const uint8_t* d, size_t n, DecodedImage& out, std::string& err)
         pos += 12 + (size_t)len;
     }
     if (w == 0 || h == 0 || ctype < 0) { err = "image: PNG without IHDR"; return false; }
+    if (w > 32768 || h > 32768) { err = "image: PNG larger than 32768 pixels on a side"; return false; }
     if (interlace) { err = "image: interlaced PNG is not supported"; return false; }
     if (depth == 16) { err = "image: 16-bit PNG maps to an R16 format the reference's Image::new_from_data does not handle (image/mod.rs:102-107)"; return false; }
     int samples = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
@@ -333,7 +342,7 @@ struct GltfLoader {
             if (uri && uri->kind == Json::Str) { if (!resolve_uri(uri->str, buffers.back())) return false; }
             else if (i == 0 && has_glb_bin) buffers.back() = glb_bin;
             else return fail("buffer without uri outside a GLB");
-            if ((double)buffers.back().size() < bufs->arr[i].number("byteLength", 0)) return fail("buffer shorter than its byteLength");
+            if (buffers.back().size() < bufs->arr[i].size_value("byteLength")) return fail("buffer shorter than its byteLength");
         }
         return true;
     }
@@ -350,17 +359,18 @@ struct GltfLoader {
         v.comp_type = (int)a->number("componentType", 0);
         const size_t csz = (v.comp_type == 5120 || v.comp_type == 5121) ? 1 : (v.comp_type == 5122 || v.comp_type == 5123) ? 2 : (v.comp_type == 5125 || v.comp_type == 5126) ? 4 : 0;
         if (!v.comps || !csz) return fail("accessor with unsupported type / componentType");
-        v.count = (size_t)a->number("count", 0);
+        v.count = a->size_value("count");
         const Json* nj = a->get("normalized");
         v.normalized = nj && nj->kind == Json::Bool && nj->b;
         const Json* bv = element("bufferViews", a->index("bufferView"));
         if (!bv) return fail("accessor without bufferView");
         const long bi = bv->index("buffer");
         if (bi < 0 || (size_t)bi >= buffers.size()) return fail("bufferView refers to a missing buffer");
-        const size_t off = (size_t)bv->number("byteOffset", 0) + (size_t)a->number("byteOffset", 0);
+        const size_t off = bv->size_value("byteOffset") + a->size_value("byteOffset");
         const size_t elem = csz * v.comps;
-        v.stride = (size_t)bv->number("byteStride", 0);
+        v.stride = bv->size_value("byteStride");
         if (v.stride == 0) v.stride = elem;
+        if (v.stride > 65536 || v.count > (1ull << 32)) return fail("accessor exceeds its buffer");
         if (v.count && off + v.stride * (v.count - 1) + elem > buffers[bi].size()) return fail("accessor exceeds its buffer");
         v.base = buffers[bi].data() + off;
         return true;
@@ -579,7 +589,7 @@ struct GltfLoader {
         }
         const Json* children = node->get("children");
         for (size_t c = 0; children && c < children->size(); c++)
-            if (!explore((long)children->arr[c].num, transform, depth + 1)) return false;
+            if (!explore(children->arr[c].kind == Json::Num && children->arr[c].num >= 0.0 && children->arr[c].num < 2147483648.0 ? (long)children->arr[c].num : -1, transform, depth + 1)) return false;
         return true;
     }
 
@@ -612,7 +622,7 @@ struct GltfLoader {
                 const Json* bv = element("bufferViews", imgs->arr[i].index("bufferView"));
                 if (!bv) return fail("image without uri or bufferView");
                 const long bi = bv->index("buffer");
-                const size_t off = (size_t)bv->number("byteOffset", 0), len = (size_t)bv->number("byteLength", 0);
+                const size_t off = bv->size_value("byteOffset"), len = bv->size_value("byteLength");
                 if (bi < 0 || (size_t)bi >= buffers.size() || off + len > buffers[bi].size()) return fail("image bufferView exceeds its buffer");
                 bytes.assign(buffers[bi].begin() + off, buffers[bi].begin() + off + len);
             }
@@ -633,7 +643,7 @@ struct GltfLoader {
         if (!scene) { char b[64]; snprintf(b, sizeof(b), "No scene with index: %ld found", scene_index); return fail(b); }
         const Json* roots = scene->get("nodes");
         for (size_t i = 0; roots && i < roots->size(); i++)
-            if (!explore((long)roots->arr[i].num, identity(), 0)) return false;
+            if (!explore(roots->arr[i].kind == Json::Num && roots->arr[i].num >= 0.0 && roots->arr[i].num < 2147483648.0 ? (long)roots->arr[i].num : -1, identity(), 0)) return false;
         for (const auto& b : out.blases) {
             const uint32_t* slots = &b.material.base_color_image;
             for (int k = 0; k < 10; k += 2) if (slots[k] != SR_NULL_TEXTURE && slots[k] >= out.textures.size()) return fail("material refers to a missing texture");
