@@ -463,7 +463,7 @@ int fast_build(SrScene* s) {
     if ((rc = upload_mesh_tables(s, &any_textured)) != SR_OK) return rc;
     if ((rc = upload_instance_tables(s)) != SR_OK) return rc;
     if ((rc = s->d_mesh_infos.upload(s->mesh_infos.data(), s->mesh_infos.size() * sizeof(SrMeshInfo))) != SR_OK) return rc;
-    const uint32_t node_cap = n / 2 + 1024;
+    const uint32_t node_cap = n + 1024;   // inner nodes of a tree with >= 2 children per node and >= 1 triangle per leaf: < n
     if ((rc = s->d_nodes.reserve((size_t)node_cap * srl::kNodeBytes)) != SR_OK || (rc = s->d_node_box.reserve((size_t)node_cap * 24)) != SR_OK ||
         (rc = s->d_tris.reserve((size_t)n * 48)) != SR_OK || (rc = s->d_shade.reserve((size_t)n * 48)) != SR_OK ||
         (rc = s->d_slot_of_gid.reserve((size_t)n * 4)) != SR_OK) return rc;

@@ -5,7 +5,7 @@
 //
 // All instances are flattened to world space (288 GB of HBM makes instancing-by-copy affordable
 // and removes the per-instance ray transform from traversal), then a binned-SAH BVH2 is built:
-// 16 bins on each of the three axes, leaves of <= 4 triangles, depth bounded so the per-lane LDS
+// 16 bins on each of the three axes, leaves of <= kLeafMax (2) triangles, depth bounded so the per-lane LDS
 // traversal stack (traverse.h kStackDepth) can never overflow. The top of the tree is built by
 // parallel tasks; nodes are emitted in depth-first order so a node's first child follows it.
 #include <algorithm>
@@ -34,7 +34,7 @@ struct Aabb {
 };
 
 constexpr int kBins = 16;
-constexpr uint32_t kLeafMax = 4;
+constexpr uint32_t kLeafMax = srl::kLeafMax;
 constexpr uint32_t kParallelMin = 1u << 15;
 
 struct Builder {

@@ -154,7 +154,7 @@ __global__ void refit_level_kernel(uint32_t* nodes, const float4* tris, float* n
 //   morton     63-bit Morton code of the centroid (21 bits per axis), radix-sorted with the triangle id (hipCUB)
 //   hierarchy  binary radix tree over the sorted codes (Karras 2012; equal codes are split by index)
 //   fit        bottom-up: box and "binary walk height" of every radix node (second arriver continues upward)
-//   collapse   top-down, one launch per level: radix subtrees of <= 4 triangles become leaves (their triangles are
+//   collapse   top-down, one launch per level: radix subtrees of <= kLeafMax triangles become leaves (their triangles are
 //              consecutive in sorted order = leaf order), inner nodes take up to 4 children by repeatedly opening
 //              the child with the largest box while the stack budget allows (same rule as bvh_build.cpp's Collapser)
 //   leaves     triangle / shade / shade_tex records in leaf order, slot_of_gid
@@ -282,7 +282,7 @@ __global__ void lbvh_fit_kernel(const float4* W, const uint32_t* sorted_gid, int
         const uint2 r = range[node];
         float* b = bin_box + (size_t)node * 6;
         for (int a = 0; a < 3; a++) { b[a] = lo[a]; b[3 + a] = hi[a]; }
-        bin_height[node] = (r.y - r.x + 1u <= 4u) ? 0u : h + 1u;
+        bin_height[node] = (r.y - r.x + 1u <= srl::kLeafMax) ? 0u : h + 1u;
         node = parent_of_inner[node];
     }
 }
@@ -294,7 +294,7 @@ __device__ __forceinline__ LbvhKid lbvh_kid(int ref, const uint2* range, const f
     if (ref < 0) { k.bin = -1; k.first = (uint32_t)~ref; k.count = 1; k.area = 0.0f; k.need = 0; return k; }
     const uint2 r = range[ref];
     const uint32_t size = r.y - r.x + 1u;
-    if (size <= 4u) { k.bin = -1; k.first = r.x; k.count = size; k.area = 0.0f; k.need = 0; return k; }
+    if (size <= srl::kLeafMax) { k.bin = -1; k.first = r.x; k.count = size; k.area = 0.0f; k.need = 0; return k; }
     const float* b = bin_box + (size_t)ref * 6;
     const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
     k.bin = ref; k.first = r.x; k.count = size; k.area = dx * dy + dy * dz + dz * dx; k.need = bin_height[ref];

@@ -75,7 +75,7 @@ struct BvhResult {
 };
 // Flatten every instance's triangles to world space (instance-major order = global triangle index).
 void flatten_instances(const std::vector<HostMesh>& meshes, const FrameInstanceData& fid, std::vector<BuildTri>& out);
-// Binned-SAH binary tree with depth bounded by `max_depth`, leaves of <= 4 triangles, collapsed into a
+// Binned-SAH binary tree with depth bounded by `max_depth`, leaves of <= kLeafMax (2) triangles, collapsed into a
 // 4-wide BVH (layout: traverse.h). max_stack = worst-case traversal stack entries for this tree.
 void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult& out);
 
