@@ -18,3 +18,9 @@ timeout -k 10 150 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT
 timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d /tmp/p_sq2 -o b -- $B --steps 5 --warmup 2 > $out/sq2.log 2>&1 && \
   find /tmp/p_sq2 -name "*counter_collection.csv" -exec cp {} $out/sq2_counter_collection.csv \;
 ls -la $out
+cd /tmp
+timeout -k 10 100 rocprofv3 --pmc TA_TA_BUSY_sum GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_ta1 -o t -- $B --steps 5 --warmup 2 > $out/ta1.log 2>&1 && \
+  find /tmp/p_ta1 -name "*counter_collection.csv" -exec cp {} $out/ta1_counter_collection.csv \; && \
+timeout -k 10 100 rocprofv3 --pmc TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum --output-format csv -d /tmp/p_ta2 -o t -- $B --steps 5 --warmup 2 > $out/ta2.log 2>&1 && \
+  find /tmp/p_ta2 -name "*counter_collection.csv" -exec cp {} $out/ta2_counter_collection.csv \;
+ls $out | wc -l

@@ -33,7 +33,10 @@ struct Aabb {
     }
 };
 
-constexpr int kBins = 16;
+#ifndef SR_SAH_BINS
+#define SR_SAH_BINS 16
+#endif
+constexpr int kBins = SR_SAH_BINS;
 constexpr uint32_t kLeafMax = srl::kLeafMax;
 constexpr uint32_t kParallelMin = 1u << 15;
 
