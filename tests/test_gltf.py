@@ -61,6 +61,24 @@ def test_reference_example_assets(path):
         assert got["blases"][0]["material"]["roughness_factor"] == 0.5 and got["blases"][0]["material"]["metallic_factor"] == 0.0
 
 
+def test_committed_glb_fixture():
+    """tests/golden/mini_scene.glb + mini_scene_expected.npz (make_gltf_golden.py): a frozen input / output pair."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    want = np.load(os.path.join(here, "mini_scene_expected.npz"))
+    got, _ = assert_same_parse(os.path.join(here, "mini_scene.glb"))
+    assert len(got["blases"]) == int(want["n_blases"]) == 2
+    for i, b in enumerate(got["blases"]):
+        assert b["vertices"].tobytes() == want["b%d_vertices" % i].tobytes()
+        assert (b["indices"] == want["b%d_indices" % i]).all()
+        assert b["material"].tobytes() == want["b%d_material" % i].tobytes()
+        assert b["emissive"].tobytes() == want["b%d_emissive" % i].tobytes()
+    assert [b for b, _ in got["instances"]] == list(want["instance_blas"]) == [0, 1, 1]
+    assert np.stack([x for _, x in got["instances"]]).tobytes() == want["instance_xf"].tobytes()
+    assert (np.array(got["samplers"], dtype=np.uint32) == want["samplers"]).all() and (np.array(got["textures"]) == want["textures"]).all()
+    assert (got["images"][0] == want["image0"]).all() and (got["images"][1] == want["image1"]).all()
+    assert len(got["blases"][0]["emissive"]) == 4 and np.allclose(got["blases"][0]["emissive"]["emission"][0], [4.0, 2.0, 1.0, 0.0])
+
+
 def _tri_mesh(b, n=5, seed=0, indices_dtype=np.uint16, stride_pad=0, uv_u16=False, tangents=True, indexed=True, uv_sets=1):
     rng = np.random.default_rng(seed)
     pos = rng.normal(size=(3 * n, 3)).astype(np.float32)
