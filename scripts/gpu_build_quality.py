@@ -27,9 +27,9 @@ def frames(tag, n=8):
 frames("host binned SAH")
 for rep in range(2):
     sc.force_next_op(abi.OP_FAST_BUILD); sc.set_instances(desc.instances)
-frames("device LBVH")
+frames("device fast build (PLOC)")
 sc.force_next_op(abi.OP_UPDATE); sc.set_instances(desc.instances)
-frames("device LBVH + refit (same)")
+frames("fast build + refit (same)")
 print("update %.2f ms" % sc.bvh_stats().build_ms)
 sc.force_next_op(abi.OP_SLOW_BUILD); sc.set_instances(desc.instances)
 sc.force_next_op(abi.OP_UPDATE); sc.set_instances(desc.instances)

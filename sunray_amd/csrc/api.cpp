@@ -89,6 +89,7 @@ struct SrScene {
     std::vector<TileSchedule> schedules;
     uint64_t schedule_clock = 0;
     int tile_scheduling = 1;                // SR_TILE_SCHEDULING=0 in the environment disables it (A/B)
+    int fast_build_ploc = 16;               // device fast build: PLOC with this search radius (default), 0 = radix tree (SR_FAST_BUILD=lbvh | ploc<r>)
     uint32_t forced_op = SR_OP_NONE;        // sr_scene_force_next_op (test / bench hook)
     bool last_build_on_device = false;
     std::vector<uint32_t> level_offsets;
@@ -190,6 +191,7 @@ int sr_scene_create(int device, SrScene** out) {
     SrScene* s = new SrScene();
     s->device = device;
     if (const char* ev = getenv("SR_TILE_SCHEDULING")) s->tile_scheduling = atoi(ev) != 0;
+    if (const char* ev = getenv("SR_FAST_BUILD")) s->fast_build_ploc = !strcmp(ev, "lbvh") ? 0 : (!strncmp(ev, "ploc", 4) && atoi(ev + 4) > 0 ? atoi(ev + 4) : 16);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
     // counters (4 x u64) + queue head, in one small allocation of their own
@@ -479,6 +481,7 @@ int fast_build(SrScene* s) {
     a.slot_of_gid = (uint32_t*)s->d_slot_of_gid.p; a.node_box = (float*)s->d_node_box.p;
     a.scratch = s->d_scratch.p; a.scratch_bytes = s->d_scratch.bytes;
     a.stack_floor = (uint32_t)srd::kStackMax; a.stack_cap = kDeviceStackCap;
+    a.ploc = s->fast_build_ploc;
     LbvhResult r;
     const int e = srk_lbvh_build(a, &r, nullptr);
     if (e > 0) return fail(SR_ERR_HIP, std::string("device BVH build failed: ") + hipGetErrorString((hipError_t)e));

@@ -27,6 +27,7 @@ struct LbvhArgs {
     uint32_t* slot_of_gid; float* node_box;              // n_tris / node_cap x 6 floats
     void* scratch; size_t scratch_bytes;
     uint32_t stack_floor, stack_cap;                     // budget = max(stack_floor, binary height); fail above stack_cap
+    int ploc;                                            // topology: 0 = binary radix tree (LBVH), r > 0 = PLOC with search radius r
 };
 struct LbvhResult {
     uint32_t n_nodes = 0, max_stack = 0, max_depth = 0;

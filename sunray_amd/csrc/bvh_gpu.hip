@@ -259,7 +259,8 @@ __global__ void lbvh_hierarchy_kernel(const unsigned long long* keys, int n, int
 // Bottom-up fit: boxes of the radix nodes and the stack height of a purely binary walk below each (0 for subtrees that
 // will become leaves), second arriver at a node continues (the first one's writes are visible after the fence).
 __global__ void lbvh_fit_kernel(const float4* W, const uint32_t* sorted_gid, int n, const int2* children, const uint32_t* parent_of_inner,
-                                const uint32_t* parent_of_leaf, const uint2* range, float* bin_box, uint32_t* bin_height, uint32_t* flags) {
+                                const uint32_t* parent_of_leaf, const uint2* range, float* bin_box, uint32_t* bin_height, uint32_t* bin_size,
+                                uint32_t* flags) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t node = parent_of_leaf[i];
@@ -282,29 +283,35 @@ __global__ void lbvh_fit_kernel(const float4* W, const uint32_t* sorted_gid, int
         const uint2 r = range[node];
         float* b = bin_box + (size_t)node * 6;
         for (int a = 0; a < 3; a++) { b[a] = lo[a]; b[3 + a] = hi[a]; }
+        bin_size[node] = r.y - r.x + 1u;
         bin_height[node] = (r.y - r.x + 1u <= srl::kLeafMax) ? 0u : h + 1u;
         node = parent_of_inner[node];
     }
 }
 
-struct LbvhKid { int bin; uint32_t first, count; float area; uint32_t need; };   // bin >= 0: inner (radix node), else leaf range
+// A child of a 4-wide node during the collapse: `ref` is a binary-tree reference (>= 0: binary node, < 0: single triangle
+// ~sorted index); subtrees of at most kLeafMax triangles become leaves.
+struct LbvhKid { int ref; uint32_t size; float area; uint32_t need; bool inner; };
 
-__device__ __forceinline__ LbvhKid lbvh_kid(int ref, const uint2* range, const float* bin_box, const uint32_t* bin_height) {
+__device__ __forceinline__ LbvhKid lbvh_kid(int ref, const uint32_t* bin_size, const float* bin_box, const uint32_t* bin_height) {
     LbvhKid k;
-    if (ref < 0) { k.bin = -1; k.first = (uint32_t)~ref; k.count = 1; k.area = 0.0f; k.need = 0; return k; }
-    const uint2 r = range[ref];
-    const uint32_t size = r.y - r.x + 1u;
-    if (size <= srl::kLeafMax) { k.bin = -1; k.first = r.x; k.count = size; k.area = 0.0f; k.need = 0; return k; }
+    k.ref = ref; k.area = 0.0f; k.need = 0; k.inner = false;
+    if (ref < 0) { k.size = 1; return k; }
+    k.size = bin_size[ref];
+    if (k.size <= srl::kLeafMax) return k;
     const float* b = bin_box + (size_t)ref * 6;
     const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
-    k.bin = ref; k.first = r.x; k.count = size; k.area = dx * dy + dy * dz + dz * dx; k.need = bin_height[ref];
+    k.area = dx * dy + dy * dz + dz * dx; k.need = bin_height[ref]; k.inner = true;
     return k;
 }
 
 // One thread per 4-wide node of the current level. counters: [0] = nodes allocated, [1] = max stack, [2] = overflow flag.
+// Leaf slots: a node owns the slot range [first_of_node, first_of_node + size) of the leaf-order arrays; its children take
+// consecutive sub-ranges in child order, and the triangles of a leaf child get their slots here (slot_of_sorted), so the
+// binary tree's subtrees need not be contiguous in Morton order (they are for the radix tree, not for PLOC).
 __global__ void lbvh_collapse_kernel(uint32_t* nodes, uint32_t level_first, uint32_t level_count, uint32_t node_cap, int* bin_of_node, uint32_t* budget_of_node,
-                                     uint32_t* prefix_of_node, const int2* children, const uint2* range, const float* bin_box, const uint32_t* bin_height,
-                                     uint32_t* counters) {
+                                     uint32_t* prefix_of_node, uint32_t* first_of_node, const int2* children, const uint32_t* bin_size, const float* bin_box,
+                                     const uint32_t* bin_height, uint32_t* slot_of_sorted, uint32_t* counters) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= level_count) return;
     const uint32_t self = level_first + t;
@@ -314,14 +321,14 @@ __global__ void lbvh_collapse_kernel(uint32_t* nodes, uint32_t level_first, uint
     LbvhKid kids[W];
     int nk = 0;
     const int2 ch = children[bin];
-    kids[nk++] = lbvh_kid(ch.x, range, bin_box, bin_height);
-    kids[nk++] = lbvh_kid(ch.y, range, bin_box, bin_height);
+    kids[nk++] = lbvh_kid(ch.x, bin_size, bin_box, bin_height);
+    kids[nk++] = lbvh_kid(ch.y, bin_size, bin_box, bin_height);
     while (nk < W) {
         int best = -1; float best_area = -1.0f;
-        for (int i = 0; i < nk; i++) if (kids[i].bin >= 0 && kids[i].area > best_area) { best_area = kids[i].area; best = i; }
+        for (int i = 0; i < nk; i++) if (kids[i].inner && kids[i].area > best_area) { best_area = kids[i].area; best = i; }
         if (best < 0) break;
-        const int2 cb = children[kids[best].bin];
-        const LbvhKid ka = lbvh_kid(cb.x, range, bin_box, bin_height), kb = lbvh_kid(cb.y, range, bin_box, bin_height);
+        const int2 cb = children[kids[best].ref];
+        const LbvhKid ka = lbvh_kid(cb.x, bin_size, bin_box, bin_height), kb = lbvh_kid(cb.y, bin_size, bin_box, bin_height);
         bool fits = ka.need + (uint32_t)nk <= budget && kb.need + (uint32_t)nk <= budget;   // with nk+1 children every subtree gets budget - nk entries
         for (int i = 0; i < nk && fits; i++) if (i != best && kids[i].need + (uint32_t)nk > budget) fits = false;
         if (!fits) break;
@@ -332,29 +339,43 @@ __global__ void lbvh_collapse_kernel(uint32_t* nodes, uint32_t level_first, uint
     for (int k = 0; k < srl::kNodeDwords; k++) q[k] = 0u;
     const uint32_t mine = prefix_of_node[self] + (uint32_t)(nk - 1);
     atomicMax(counters + 1, mine);
+    uint32_t first = first_of_node[self];
     for (int i = 0; i < W; i++) {
         uint32_t ref = 0xFFFFFFFFu;                              // leaf_ref(0, 0): unused child
         if (i < nk) {
-            if (kids[i].bin >= 0) {
+            if (kids[i].inner) {
                 const uint32_t idx = atomicAdd(counters + 0, 1u);
                 if (idx < node_cap) {
-                    bin_of_node[idx] = kids[i].bin;
+                    bin_of_node[idx] = kids[i].ref;
                     budget_of_node[idx] = budget - (uint32_t)(nk - 1);
                     prefix_of_node[idx] = mine;
+                    first_of_node[idx] = first;
                     ref = idx;
                 } else { atomicExch(counters + 2, 1u); }
-            } else ref = ~((kids[i].first << 3) | kids[i].count);
+            } else {
+                ref = ~((first << 3) | kids[i].size);
+                // slots of the leaf's triangles: walk the (at most kLeafMax-triangle) binary subtree
+                int stack[8]; int sp = 0; uint32_t slot = first;
+                stack[sp++] = kids[i].ref;
+                while (sp > 0) {
+                    const int r = stack[--sp];
+                    if (r < 0) slot_of_sorted[~r] = slot++;
+                    else { const int2 c2 = children[r]; if (sp < 7) { stack[sp++] = c2.y; stack[sp++] = c2.x; } }
+                }
+            }
+            first += kids[i].size;
         }
         q[srl::kChildOffset + i] = ref;
     }
 }
 
-// Leaf-order records: the sorted order is the leaf order.
-__global__ void lbvh_leaves_kernel(const float4* W, const float4* cent, const uint32_t* sorted_gid, uint32_t n_tris, const SrMeshInfo* meshes,
-                                   const FlatInstance* instances, float4* tris, float4* shade, float4* shade_tex, uint32_t* slot_of_gid) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n_tris) return;
-    const uint32_t gid = sorted_gid[slot];
+// Leaf-order records of one triangle (by sorted index): its slot was assigned by the collapse.
+__global__ void lbvh_leaves_kernel(const float4* W, const float4* cent, const uint32_t* sorted_gid, const uint32_t* slot_of_sorted, uint32_t n_tris,
+                                   const SrMeshInfo* meshes, const FlatInstance* instances, float4* tris, float4* shade, float4* shade_tex, uint32_t* slot_of_gid) {
+    const uint32_t s_idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s_idx >= n_tris) return;
+    const uint32_t slot = slot_of_sorted[s_idx];
+    const uint32_t gid = sorted_gid[s_idx];
     for (int k = 0; k < 3; k++) tris[(size_t)slot * 3 + k] = W[(size_t)gid * 3 + k];
     slot_of_gid[gid] = slot;
     const uint32_t ii = __float_as_uint(cent[gid].w);
@@ -376,6 +397,72 @@ __global__ void lbvh_leaves_kernel(const float4* W, const float4* cent, const ui
         q[4] = make_float4(v[1]->tangent[0], v[1]->tangent[1], v[1]->tangent[2], v[2]->tangent[0]);
         q[5] = make_float4(v[2]->tangent[1], v[2]->tangent[2], 0.0f, 0.0f);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) as the topology of the fast build: bottom-up
+// agglomeration of the Morton-ordered clusters. Every iteration each cluster finds, among its `radius` neighbours on
+// either side, the one whose union with it has the smallest surface area; mutual nearest neighbours merge into a binary
+// node (box, size and binary-walk height are known at once), the survivors are compacted in order, until one is left.
+// Build quality is close to the top-down SAH build at a small multiple of the radix tree's cost.
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ void ploc_init_kernel(const float4* W, const uint32_t* sorted_gid, uint32_t n, int* cid, float* cbox) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    tri_box(W, sorted_gid[i], lo, hi);
+    cid[i] = ~(int)i;
+    float* b = cbox + (size_t)i * 6;
+    for (int a = 0; a < 3; a++) { b[a] = lo[a]; b[3 + a] = hi[a]; }
+}
+
+__global__ void ploc_nn_kernel(const float* cbox, uint32_t m, uint32_t radius, uint32_t* nn) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const float* b = cbox + (size_t)i * 6;
+    const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
+    const uint32_t j0 = i > radius ? i - radius : 0u, j1 = min(m - 1u, i + radius);
+    float best = INFINITY; uint32_t best_j = i;
+    for (uint32_t j = j0; j <= j1; j++) {
+        if (j == i) continue;
+        const float* c = cbox + (size_t)j * 6;
+        const float dx = fmaxf(hi[0], c[3]) - fminf(lo[0], c[0]), dy = fmaxf(hi[1], c[4]) - fminf(lo[1], c[1]), dz = fmaxf(hi[2], c[5]) - fminf(lo[2], c[2]);
+        const float area = dx * dy + dy * dz + dz * dx;
+        if (area < best) { best = area; best_j = j; }        // ties: the lower index (scan order)
+    }
+    nn[i] = best_j;
+}
+
+// Mutual nearest neighbours merge (the lower index keeps the merged cluster, the higher one is dropped).
+__global__ void ploc_merge_kernel(const uint32_t* nn, uint32_t m, int* cid, float* cbox, uint32_t* valid, int2* children, float* bin_box, uint32_t* bin_size,
+                                  uint32_t* bin_height, uint32_t* node_counter) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t j = nn[i];
+    if (j == i || nn[j] != i) { valid[i] = 1u; return; }
+    if (j < i) { valid[i] = 0u; return; }
+    const int ci = cid[i], cj = cid[j];
+    const uint32_t node = atomicAdd(node_counter, 1u);
+    const uint32_t si = ci < 0 ? 1u : bin_size[ci], sj = cj < 0 ? 1u : bin_size[cj];
+    const uint32_t hi_ = ci < 0 ? 0u : bin_height[ci], hj = cj < 0 ? 0u : bin_height[cj];
+    children[node] = make_int2(ci, cj);
+    bin_size[node] = si + sj;
+    bin_height[node] = (si + sj <= srl::kLeafMax) ? 0u : max(hi_, hj) + 1u;
+    float* bi = cbox + (size_t)i * 6;
+    const float* bj = cbox + (size_t)j * 6;
+    float* nb = bin_box + (size_t)node * 6;
+    for (int a = 0; a < 3; a++) { bi[a] = fminf(bi[a], bj[a]); bi[3 + a] = fmaxf(bi[3 + a], bj[3 + a]); nb[a] = bi[a]; nb[3 + a] = bi[3 + a]; }
+    cid[i] = (int)node;
+    valid[i] = 1u;
+}
+
+__global__ void ploc_compact_kernel(const int* cid, const float* cbox, const uint32_t* valid, const uint32_t* pos, uint32_t m, int* cid_out, float* cbox_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m || !valid[i]) return;
+    const uint32_t p = pos[i];
+    cid_out[p] = cid[i];
+    for (int a = 0; a < 6; a++) cbox_out[(size_t)p * 6 + a] = cbox[(size_t)i * 6 + a];
 }
 
 }  // namespace srd
@@ -414,48 +501,85 @@ int srk_lbvh_build(const LbvhArgs& a, LbvhResult* out, hipStream_t stream) {
     uint32_t* vals_a = (uint32_t*)take((size_t)n * 4);
     uint32_t* vals_b = (uint32_t*)take((size_t)n * 4);
     int2* children = (int2*)take((size_t)n * 8);
-    uint2* range = (uint2*)take((size_t)n * 8);
-    uint32_t* parent_inner = (uint32_t*)take((size_t)n * 4);
+    uint2* range = (uint2*)take((size_t)n * 8);             // radix tree only; PLOC: nn | valid
+    uint32_t* parent_inner = (uint32_t*)take((size_t)n * 4);   // radix tree only; PLOC: scan output
     uint32_t* parent_leaf = (uint32_t*)take((size_t)n * 4);
     float* bin_box = (float*)take((size_t)n * 24);
     uint32_t* bin_height = (uint32_t*)take((size_t)n * 4);
+    uint32_t* bin_size = (uint32_t*)take((size_t)n * 4);
     uint32_t* flags = (uint32_t*)take((size_t)n * 4);
+    uint32_t* slot_of_sorted = (uint32_t*)take((size_t)n * 4);
     int* bin_of_node = (int*)take((size_t)a.node_cap * 4);
     uint32_t* budget_of_node = (uint32_t*)take((size_t)a.node_cap * 4);
     uint32_t* prefix_of_node = (uint32_t*)take((size_t)a.node_cap * 4);
-    uint32_t* small = (uint32_t*)take(256);          // [0..5] bounds, [8..10] counters
-    size_t cub_bytes = 0;
+    uint32_t* first_of_node = (uint32_t*)take((size_t)a.node_cap * 4);
+    uint32_t* small = (uint32_t*)take(256);          // [0..5] bounds, [8..10] counters, [12] PLOC node counter
+    // PLOC cluster arrays (double-buffered)
+    int* cid[2] = {nullptr, nullptr}; float* cbox[2] = {nullptr, nullptr};
+    if (a.ploc) for (int k = 0; k < 2; k++) { cid[k] = (int*)take((size_t)n * 4); cbox[k] = (float*)take((size_t)n * 24); }
+    size_t cub_bytes = 0, scan_bytes = 0;
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, stream);
     if (e != hipSuccess) return (int)e;
-    void* cub_tmp = take(cub_bytes);
+    if (a.ploc && (e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, stream)) != hipSuccess) return (int)e;
+    void* cub_tmp = take(cub_bytes > scan_bytes ? cub_bytes : scan_bytes);
     if (off > a.scratch_bytes) return (int)hipErrorOutOfMemory;
 
     const uint32_t init[16] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     if ((e = hipMemcpyAsync(small, init, sizeof(init), hipMemcpyHostToDevice, stream)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(flags, 0, (size_t)n * 4, stream)) != hipSuccess) return (int)e;
     lbvh_prims_kernel<<<gt, bt, 0, stream>>>(a.meshes, a.instances, a.n_instances, n, W, cent, small);
     lbvh_morton_kernel<<<gt, bt, 0, stream>>>(cent, small, n, keys_a, vals_a);
     if ((e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, stream)) != hipSuccess) return (int)e;
-    lbvh_hierarchy_kernel<<<gt, bt, 0, stream>>>(keys_b, (int)n, children, parent_inner, parent_leaf, range);
-    lbvh_fit_kernel<<<gt, bt, 0, stream>>>(W, vals_b, (int)n, children, parent_inner, parent_leaf, range, bin_box, bin_height, flags);
-    // root of the 4-wide tree = radix node 0; its budget is the binary height, at least the regular stack size
+    int root_bin = 0;
+    if (!a.ploc) {
+        if ((e = hipMemsetAsync(flags, 0, (size_t)n * 4, stream)) != hipSuccess) return (int)e;
+        lbvh_hierarchy_kernel<<<gt, bt, 0, stream>>>(keys_b, (int)n, children, parent_inner, parent_leaf, range);
+        lbvh_fit_kernel<<<gt, bt, 0, stream>>>(W, vals_b, (int)n, children, parent_inner, parent_leaf, range, bin_box, bin_height, bin_size, flags);
+    } else {
+        uint32_t* nn = (uint32_t*)range;
+        uint32_t* valid = nn + n;
+        uint32_t* pos = parent_inner;
+        uint32_t* node_counter = small + 12;
+        ploc_init_kernel<<<gt, bt, 0, stream>>>(W, vals_b, n, cid[0], cbox[0]);
+        uint32_t m = n;
+        int cur = 0, guard = 0;
+        while (m > 1) {
+            const dim3 gm((m + B - 1) / B);
+            ploc_nn_kernel<<<gm, bt, 0, stream>>>(cbox[cur], m, (uint32_t)a.ploc, nn);
+            ploc_merge_kernel<<<gm, bt, 0, stream>>>(nn, m, cid[cur], cbox[cur], valid, children, bin_box, bin_size, bin_height, node_counter);
+            if ((e = hipcub::DeviceScan::ExclusiveSum(cub_tmp, scan_bytes, valid, pos, (int)m, stream)) != hipSuccess) return (int)e;
+            ploc_compact_kernel<<<gm, bt, 0, stream>>>(cid[cur], cbox[cur], valid, pos, m, cid[cur ^ 1], cbox[cur ^ 1]);
+            uint32_t tail[2];      // new count = pos[m-1] + valid[m-1]
+            if ((e = hipMemcpyAsync(&tail[0], pos + (m - 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;
+            if ((e = hipMemcpyAsync(&tail[1], valid + (m - 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
+            const uint32_t m_new = tail[0] + tail[1];
+            if (m_new >= m || ++guard > 4096) return -1;     // no progress: cannot happen (the closest pair is always mutual)
+            m = m_new;
+            cur ^= 1;
+        }
+        if ((e = hipMemcpyAsync(&root_bin, cid[cur], 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
+        if (root_bin < 0) return -1;
+    }
+    // root of the 4-wide tree = the binary root; its budget is the binary height, at least the regular stack size
     uint32_t root_height = 0;
-    if ((e = hipMemcpyAsync(&root_height, bin_height, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;
+    if ((e = hipMemcpyAsync(&root_height, bin_height + root_bin, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
     if (root_height > a.stack_cap) return -1;
     const uint32_t budget = root_height > a.stack_floor ? root_height : a.stack_floor;
-    const int root_init[1] = {0};
     const uint32_t zero = 0;
-    (void)hipMemcpyAsync(bin_of_node, root_init, 4, hipMemcpyHostToDevice, stream);
+    (void)hipMemcpyAsync(bin_of_node, &root_bin, 4, hipMemcpyHostToDevice, stream);
     (void)hipMemcpyAsync(budget_of_node, &budget, 4, hipMemcpyHostToDevice, stream);
     (void)hipMemcpyAsync(prefix_of_node, &zero, 4, hipMemcpyHostToDevice, stream);
+    (void)hipMemcpyAsync(first_of_node, &zero, 4, hipMemcpyHostToDevice, stream);
     out->level_ranges.clear();
     uint32_t level_first = 0, level_count = 1;
     uint32_t* counters = small + 8;
     while (level_count) {
         out->level_ranges.emplace_back(level_first, level_count);
         lbvh_collapse_kernel<<<dim3((level_count + 63) / 64), dim3(64), 0, stream>>>((uint32_t*)a.nodes, level_first, level_count, a.node_cap, bin_of_node,
-                                                                                       budget_of_node, prefix_of_node, children, range, bin_box, bin_height, counters);
+                                                                                       budget_of_node, prefix_of_node, first_of_node, children, bin_size, bin_box,
+                                                                                       bin_height, slot_of_sorted, counters);
         uint32_t c[3];
         if ((e = hipMemcpyAsync(c, counters, 12, hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
@@ -467,7 +591,7 @@ int srk_lbvh_build(const LbvhArgs& a, LbvhResult* out, hipStream_t stream) {
         if (out->level_ranges.size() > 128) return -1;
     }
     out->max_depth = (uint32_t)out->level_ranges.size();
-    lbvh_leaves_kernel<<<gt, bt, 0, stream>>>(W, cent, vals_b, n, a.meshes, a.instances, a.tris, a.shade, a.shade_tex, a.slot_of_gid);
+    lbvh_leaves_kernel<<<gt, bt, 0, stream>>>(W, cent, vals_b, slot_of_sorted, n, a.meshes, a.instances, a.tris, a.shade, a.shade_tex, a.slot_of_gid);
     for (size_t l = out->level_ranges.size(); l-- > 0;)
         refit_level_kernel<<<dim3((out->level_ranges[l].second + 63) / 64), dim3(64), 0, stream>>>((uint32_t*)a.nodes, a.tris, a.node_box, nullptr,
                                                                                                      out->level_ranges[l].first, out->level_ranges[l].second);
@@ -477,8 +601,9 @@ int srk_lbvh_build(const LbvhArgs& a, LbvhResult* out, hipStream_t stream) {
 }
 
 size_t srk_lbvh_scratch_bytes(uint32_t n_tris, uint32_t node_cap) {
-    size_t cub_bytes = 0;
+    size_t cub_bytes = 0, scan_bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr,
                                              (uint32_t*)nullptr, (int)n_tris, 0, 63, nullptr);
-    return (size_t)n_tris * (48 + 16 + 16 + 8 + 8 + 8 + 4 + 4 + 24 + 4 + 4) + (size_t)node_cap * 12 + cub_bytes + 64 * 256;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n_tris, nullptr);
+    return (size_t)n_tris * (48 + 16 + 16 + 8 + 8 + 8 + 4 + 4 + 24 + 4 + 4 + 4 + 4 + 2 * (4 + 24)) + (size_t)node_cap * 16 + std::max(cub_bytes, scan_bytes) + 96 * 256;
 }
