@@ -23,7 +23,8 @@ for f in range(4, 24):
 torch.cuda.synchronize()
 full = (time.perf_counter() - t0) / 20 * 1e3
 rows = np.repeat((sc.tile_row_costs(0, W, 0, H) + sc.tile_row_costs(1, W, 0, H)) / 8.0, 8)[:H]
-cases = [("max_share %.1f, 2 frames in flight" % ms, sd.balanced_bounds(rows, world, max_share=ms), True) for ms in (1.5, 2.5, 4.0)]
+cases = [("equal rows, sequential", [min(r * ((H + world - 1) // world), H) for r in range(world)] + [H], False),
+         ("measured-cost strips, 2 frames in flight", sd.balanced_bounds(rows, world), True)]
 for name, bounds, piped in cases:
     times = []
     for rank in range(world):
