@@ -5,11 +5,11 @@
 //   ris_kernel                               — ray_gen_ris.slang:12-440   (K1, K7, K8, K9)
 //   final_kernel                             — ray_gen_final.slang:11-436 (K1, K10)
 //
-// Launch geometry: 256-thread workgroups (4 waves of 64). In the per-pixel passes a workgroup owns a
-// 16x16 pixel tile and each wave an 8x8 sub-tile (coherent primary rays per wave); workgroups are
-// dealt to screen tiles XCD-aware: blocks b and b+8 share an XCD (round-robin dispatch), so XCD x
-// gets the contiguous tile range [x*per_xcd, (x+1)*per_xcd) and its private 4 MiB L2 holds the part
-// of the BVH under that band of the screen.
+// Launch geometry: the ray-queue and shade kernels use 256-thread workgroups; the two per-pixel passes use ONE WAVE per
+// workgroup, owning an 8x8 pixel tile (coherent primary rays per wave; a 4-wave workgroup would hold its LDS until its
+// slowest wave finished). Workgroups are dealt to screen tiles XCD-aware: blocks b and b+8 share an XCD (round-robin
+// dispatch), XCD x owns column band x of the image, so its private 4 MiB L2 holds the part of the BVH under that band;
+// inside a band the rows are swept from the expensive end to the cheap end (thread_pixel, tile_order_kernel).
 #include "kernels.h"
 
 namespace srd {
@@ -191,10 +191,10 @@ SRD LightTri fetch_light(const DevScene& sc, uint32_t idx) {
 // share an XCD under round-robin dispatch), walked row-major inside the band. Cost varies mostly with
 // image row (distance to the terrain), so column bands give every XCD the same mix of rows, while the
 // tiles an XCD works on at any moment stay neighbours and share its 4 MiB L2.
-// Tiles of one band are taken in the order of the previous launch's measured cost, most expensive first (longest-
-// processing-time-first): the launch then drains with cheap tiles instead of ending on a front of expensive ones
-// (a frame's cost is spatially correlated: sky rows finish in a fraction of the time of terrain rows). Scheduling
-// only — results do not depend on it. `tile` = index of the tile inside its band, also the index of its cost slot.
+// The order of a band's tiles comes from tile_order (tile_order_kernel, derived from the previous launch's measured
+// costs): the launch then drains with cheap tiles instead of ending on a front of expensive ones (a frame's cost is
+// spatially correlated: sky rows finish in a fraction of the time of terrain rows). Scheduling only — results do not
+// depend on it. `tile` = index of the tile inside its band, also the index of its cost slot.
 SRD bool thread_pixel(const PassArgs& a, uint32_t& px, uint32_t& py, uint32_t& cost_slot) {
     const uint32_t b = blockIdx.x;
     const uint32_t xcd = b & 7u, k = b >> 3;

@@ -169,7 +169,6 @@ SRD int pick(int4 c, uint32_t i) {   // two levels of selects (v_cndmask), no br
     const int hi = (i & 1u) ? c.w : c.z;
     return (i & 2u) ? hi : lo;
 }
-SRD void cswap(uint32_t& a, uint32_t& b) { const uint32_t lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
 
 template <bool ANY, bool STATS>
 SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHit& hit, int* stack_base, int stride, TravStats& st) {
