@@ -548,6 +548,10 @@ int sr_default_noise_texture(uint32_t w, uint32_t h, uint32_t seed, uint8_t* out
 int sr_scene_read_tile_row_costs(SrScene* scene, int which, uint32_t width, uint32_t y0, uint32_t rows, double* out,
                                  uint32_t cap, uint32_t* n_tile_rows);
 
+/* The same measurement per tile (8x8 pixels), in the band-major order the kernels use: tuning diagnostics. */
+int sr_scene_read_tile_costs(SrScene* scene, int which, uint32_t width, uint32_t y0, uint32_t rows, uint32_t* out,
+                             uint32_t cap, uint32_t* n_tiles);
+
 /* Ray counters since the last reset (device-side atomics, read back synchronously). */
 int sr_scene_reset_counters(SrScene* scene, void* stream);
 int sr_scene_read_counters(SrScene* scene, void* stream, SrRayCounters* out);

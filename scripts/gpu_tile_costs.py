@@ -1,0 +1,24 @@
+"""Distribution of the per-wave (8x8 tile) cycle counts of both passes on the bench frame: how long are the slowest waves?"""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from sunray_amd import abi, scenes, runtime as rt
+from sunray_amd._lib import lib, check
+W, H = 1920, 1080
+desc = scenes.heightfield(708)
+sc = rt.Scene(0).load(desc)
+fr = rt.DeviceFrame(W, H, scenes.white_noise_rgba8())
+cfg = abi.SrTraceConfig.reference()
+prev = None
+sc.enable_timing(True)
+for f in range(8):
+    m = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, prev); prev = list(m.view_proj)
+    sc.trace_ris(fr, m, f, cfg); sc.trace_final(fr, m, f, cfg)
+    a, _ = sc.read_timing(0); b, _ = sc.read_timing(1)
+for which, name, ms in ((0, "ris", a), (1, "final", b)):
+    out = np.zeros(40000, dtype=np.uint32); n = C.c_uint32()
+    check(lib().sr_scene_read_tile_costs(sc._h, which, W, 0, H, out.ctypes.data_as(C.c_void_p), len(out), C.byref(n)))
+    c = out[:n.value].astype(np.float64) / 2100.0    # s_memtime ticks are shader cycles (~2.1 GHz under this load) -> microseconds
+    q = np.percentile(c, [50, 90, 99, 99.9, 100])
+    print("%-5s kernel %.3f ms | wave duration us: mean %.0f median %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f | waves longer than half the kernel: %d of %d" % (
+        name, ms, c.mean(), q[0], q[1], q[2], q[3], q[4], int((c > ms * 500).sum()), len(c)))

@@ -849,6 +849,22 @@ int sr_scene_read_tile_row_costs(SrScene* s, int which, uint32_t width, uint32_t
     return SR_OK;
 }
 
+// The same data per tile (band-major order of thread_pixel): tuning diagnostics.
+int sr_scene_read_tile_costs(SrScene* s, int which, uint32_t width, uint32_t y0, uint32_t rows, uint32_t* out, uint32_t cap, uint32_t* n_tiles_out) {
+    if (!s || !out || !n_tiles_out) return fail(SR_ERR_INVALID_ARG, "sr_scene_read_tile_costs: null argument");
+    SrScene::TileSchedule* sched = nullptr;
+    for (auto& ts : s->schedules) if (ts.which == which && ts.width == width && ts.y0 == y0 && ts.y1 == y0 + rows) sched = &ts;
+    if (!sched) return fail(SR_ERR_STATE, "sr_scene_read_tile_costs: no launch of this pass with this geometry yet");
+    const uint32_t n_tiles = srk_pass_tile_count(width, rows);
+    *n_tiles_out = n_tiles;
+    if (cap < n_tiles) return fail(SR_ERR_INVALID_ARG, "sr_scene_read_tile_costs: output too small");
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, sched->cost.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
 int sr_trace_ris(const SrRtParams* params, void* stream) { return run_pass(params, 0, stream); }
 int sr_trace_final(const SrRtParams* params, void* stream) { return run_pass(params, 1, stream); }
 
