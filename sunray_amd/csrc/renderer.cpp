@@ -19,13 +19,19 @@ struct SrRenderer {
     SrScene* scene = nullptr;
     uint32_t width = 0, height = 0;
     // frame buffers (the reference's transient G-buffer images + temporal resources, lib.rs:320-331,1492-1516)
-    float* raw_color = nullptr;
-    uint16_t* depth = nullptr;
-    uint32_t *normal = nullptr, *diffuse = nullptr, *motion = nullptr;
+    // MAX_FRAMES_IN_FLIGHT = 2 (lib.rs:71): the images one frame writes and reads are double-buffered, so raytracing_ris of
+    // frame f+1 (own stream) overlaps raytracing_final + the post chain of frame f. The reservoir, accumulation and denoise
+    // ping-pongs carry history from frame to frame and stay single sets.
+    float* raw_color[2] = {nullptr, nullptr};
+    uint16_t* depth[2] = {nullptr, nullptr};
+    uint32_t *normal[2] = {nullptr, nullptr}, *diffuse[2] = {nullptr, nullptr}, *motion[2] = {nullptr, nullptr};
     SrReservoir* reservoirs[2] = {nullptr, nullptr};
     SrReservoirGI* reservoirs_gi[2] = {nullptr, nullptr};
     uint32_t *accum[2] = {nullptr, nullptr}, *denoise[2] = {nullptr, nullptr};
-    uint32_t* output = nullptr;
+    uint32_t* output[2] = {nullptr, nullptr};
+    hipStream_t s_ris = nullptr, s_final = nullptr;
+    hipEvent_t ev_in = nullptr, ev_ris[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    int last_set = 0;
     uint8_t* blue_noise = nullptr;
     // per-frame state
     float prev_view_proj[16];       // zero on the first frame (lib.rs:410), NOT reset by resize
@@ -36,7 +42,6 @@ struct SrRenderer {
     std::vector<uint32_t> last_counts;
     std::vector<SrTransform> last_transforms;
     bool instances_valid = false;
-    hipEvent_t frame_done = nullptr;
     // asset groups of load_scene (lib.rs:802-828): group -> BLAS keys; images stay resident (slots are never reused)
     uint64_t next_group = 0;
     std::map<uint64_t, std::vector<uint64_t>> scene_groups;
@@ -57,12 +62,13 @@ int rfail(int code, const std::string& msg) { return srh::set_error(code, msg); 
 #define R_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return rfail(e_ == hipErrorOutOfMemory ? SR_ERR_OOM : SR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
 void free_images(SrRenderer* r) {
-    void* ptrs[] = {r->raw_color, r->depth, r->normal, r->diffuse, r->motion, r->reservoirs[0], r->reservoirs[1],
-                    r->reservoirs_gi[0], r->reservoirs_gi[1], r->accum[0], r->accum[1], r->denoise[0], r->denoise[1], r->output};
+    void* ptrs[] = {r->raw_color[0], r->raw_color[1], r->depth[0], r->depth[1], r->normal[0], r->normal[1], r->diffuse[0], r->diffuse[1],
+                    r->motion[0], r->motion[1], r->reservoirs[0], r->reservoirs[1], r->reservoirs_gi[0], r->reservoirs_gi[1], r->accum[0],
+                    r->accum[1], r->denoise[0], r->denoise[1], r->output[0], r->output[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    r->raw_color = nullptr; r->depth = nullptr; r->normal = r->diffuse = r->motion = nullptr;
+    for (int k = 0; k < 2; k++) { r->raw_color[k] = nullptr; r->depth[k] = nullptr; r->normal[k] = r->diffuse[k] = r->motion[k] = nullptr; r->output[k] = nullptr; }
     r->reservoirs[0] = r->reservoirs[1] = nullptr; r->reservoirs_gi[0] = r->reservoirs_gi[1] = nullptr;
-    r->accum[0] = r->accum[1] = r->denoise[0] = r->denoise[1] = nullptr; r->output = nullptr;
+    r->accum[0] = r->accum[1] = r->denoise[0] = r->denoise[1] = nullptr;
 }
 
 template <typename T>
@@ -75,8 +81,9 @@ int alloc_zero(T** p, size_t n) {
 int alloc_images(SrRenderer* r, uint32_t w, uint32_t h) {
     const size_t n = (size_t)w * h;
     int rc;
-    if ((rc = alloc_zero(&r->raw_color, n * 4)) || (rc = alloc_zero(&r->depth, n)) || (rc = alloc_zero(&r->normal, n)) ||
-        (rc = alloc_zero(&r->diffuse, n)) || (rc = alloc_zero(&r->motion, n)) || (rc = alloc_zero(&r->output, n))) return rc;
+    for (int i = 0; i < 2; i++)
+        if ((rc = alloc_zero(&r->raw_color[i], n * 4)) || (rc = alloc_zero(&r->depth[i], n)) || (rc = alloc_zero(&r->normal[i], n)) ||
+            (rc = alloc_zero(&r->diffuse[i], n)) || (rc = alloc_zero(&r->motion[i], n)) || (rc = alloc_zero(&r->output[i], n))) return rc;
     for (int i = 0; i < 2; i++)
         if ((rc = alloc_zero(&r->reservoirs[i], n)) || (rc = alloc_zero(&r->reservoirs_gi[i], n)) ||
             (rc = alloc_zero(&r->accum[i], n)) || (rc = alloc_zero(&r->denoise[i], n))) return rc;
@@ -118,7 +125,10 @@ int sr_renderer_create(int device, uint32_t width, uint32_t height, SrRenderer**
     std::vector<uint8_t> noise(128 * 128 * 4);
     sr_default_noise_texture(128, 128, 7, noise.data());
     if (hipMalloc((void**)&r->blue_noise, noise.size()) != hipSuccess || hipMemcpy(r->blue_noise, noise.data(), noise.size(), hipMemcpyHostToDevice) != hipSuccess ||
-        hipEventCreate(&r->frame_done) != hipSuccess) {
+        hipStreamCreateWithFlags(&r->s_ris, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&r->s_final, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ev_ris[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->ev_ris[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ev_done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->ev_done[1], hipEventDisableTiming) != hipSuccess) {
         free_images(r); sr_scene_destroy(r->scene); delete r;
         return rfail(SR_ERR_HIP, "Renderer::new: blue-noise upload failed");
     }
@@ -132,7 +142,9 @@ int sr_renderer_destroy(SrRenderer* r) {
     (void)hipDeviceSynchronize();
     free_images(r);
     if (r->blue_noise) (void)hipFree(r->blue_noise);
-    if (r->frame_done) (void)hipEventDestroy(r->frame_done);
+    for (hipEvent_t e : {r->ev_in, r->ev_ris[0], r->ev_ris[1], r->ev_done[0], r->ev_done[1]}) if (e) (void)hipEventDestroy(e);
+    if (r->s_ris) (void)hipStreamDestroy(r->s_ris);
+    if (r->s_final) (void)hipStreamDestroy(r->s_final);
     sr_scene_destroy(r->scene);
     delete r;
     return SR_OK;
@@ -166,8 +178,10 @@ int sr_renderer_set_config(SrRenderer* r, const SrTraceConfig* cfg) {
 }
 
 // Renderer::render (lib.rs:984-1232): one frame = TLAS (re)build when the instance list changed ->
-// raytracing_ris -> raytracing_final -> temporal_accumulation -> denoise_0..3 -> postprocess, all
-// enqueued on `stream`; returns the frame number to wait on.
+// raytracing_ris -> raytracing_final -> temporal_accumulation -> denoise_0..3 -> postprocess, enqueued on the
+// renderer's own two streams after whatever the caller has enqueued on `stream`; returns the frame number to wait
+// on. Two frames may be in flight (MAX_FRAMES_IN_FLIGHT, lib.rs:71): submit frame f+1 before waiting for frame f and
+// its RIS pass overlaps frame f's final pass and post chain. Results equal back-to-back execution.
 int sr_renderer_render(SrRenderer* r, const float cam_pos[3], const float cam_target[3], float fov_y, const uint64_t* keys,
                        const uint32_t* counts, uint32_t n_keys, const SrTransform* transforms, void* stream, uint64_t* out_frame) {
     if (!r || !cam_pos || !cam_target) return rfail(SR_ERR_INVALID_ARG, "Renderer::render: null argument");
@@ -194,10 +208,15 @@ int sr_renderer_render(SrRenderer* r, const float cam_pos[3], const float cam_ta
     int rc = sr_camera_matrices(cam_pos, cam_target, fov_y, r->width, r->height, r->prev_view_proj, &m);   // lib.rs:1017-1048
     if (rc != SR_OK) return rc;
     memcpy(r->prev_view_proj, m.view_proj, sizeof(r->prev_view_proj));                                     // history for the NEXT frame
+    // image set of this frame; the orderings that remain: RIS(f) -> final(f) -> post(f), RIS(f) -> RIS(f+1) and post(f-2) -> RIS(f)
+    const int k = (int)(r->relative_frame_count & 1u);
+    R_HIP(hipEventRecord(r->ev_in, (hipStream_t)stream));           // whatever the caller enqueued on `stream` comes first
+    R_HIP(hipStreamWaitEvent(r->s_ris, r->ev_in, 0));
+    R_HIP(hipStreamWaitEvent(r->s_ris, r->ev_done[k], 0));          // frame f-2 no longer reads this image set
     SrRtParams p;
     memset(&p, 0, sizeof(p));
     p.scene = r->scene;
-    p.raw_color = r->raw_color; p.depth_img = r->depth; p.normal_img = r->normal; p.diffuse_img = r->diffuse; p.motion_vec_img = r->motion;
+    p.raw_color = r->raw_color[k]; p.depth_img = r->depth[k]; p.normal_img = r->normal[k]; p.diffuse_img = r->diffuse[k]; p.motion_vec_img = r->motion[k];
     p.matrices = &m;
     p.blue_noise_tex = r->blue_noise; p.blue_noise_w = 128; p.blue_noise_h = 128;
     p.reservoirs[0] = r->reservoirs[0]; p.reservoirs[1] = r->reservoirs[1];
@@ -205,20 +224,23 @@ int sr_renderer_render(SrRenderer* r, const float cam_pos[3], const float cam_ta
     p.frame_count = r->relative_frame_count;
     p.width = r->width; p.height = r->height;
     p.config = r->config;
-    if (p.config.enable_restir && (rc = sr_trace_ris(&p, stream)) != SR_OK) return rc;
-    if ((rc = sr_trace_final(&p, stream)) != SR_OK) return rc;
+    if (p.config.enable_restir && (rc = sr_trace_ris(&p, r->s_ris)) != SR_OK) return rc;
+    R_HIP(hipEventRecord(r->ev_ris[k], r->s_ris));
+    R_HIP(hipStreamWaitEvent(r->s_final, r->ev_ris[k], 0));
+    if ((rc = sr_trace_final(&p, r->s_final)) != SR_OK) return rc;
     SrPostParams q;
     memset(&q, 0, sizeof(q));
-    q.raw_color = r->raw_color; q.motion_vec_img = r->motion; q.depth_img = r->depth; q.normal_img = r->normal; q.diffuse_img = r->diffuse;
+    q.raw_color = r->raw_color[k]; q.motion_vec_img = r->motion[k]; q.depth_img = r->depth[k]; q.normal_img = r->normal[k]; q.diffuse_img = r->diffuse[k];
     q.accum[0] = r->accum[0]; q.accum[1] = r->accum[1]; q.denoise[0] = r->denoise[0]; q.denoise[1] = r->denoise[1];
-    q.output_rgba8 = r->output;
+    q.output_rgba8 = r->output[k];
     q.frame_count = r->relative_frame_count; q.width = r->width; q.height = r->height;
     q.exposure = 1.0f;        // EXPOSURE (lib.rs:44)
     q.denoise_passes = 4;     // DENOISE_PASSES (lib.rs:42)
-    if ((rc = sr_post_temporal(&q, stream)) != SR_OK) return rc;
-    if ((rc = sr_post_denoise(&q, stream)) != SR_OK) return rc;
-    if ((rc = sr_post_tonemap(&q, stream)) != SR_OK) return rc;
-    R_HIP(hipEventRecord(r->frame_done, (hipStream_t)stream));
+    if ((rc = sr_post_temporal(&q, r->s_final)) != SR_OK) return rc;
+    if ((rc = sr_post_denoise(&q, r->s_final)) != SR_OK) return rc;
+    if ((rc = sr_post_tonemap(&q, r->s_final)) != SR_OK) return rc;
+    R_HIP(hipEventRecord(r->ev_done[k], r->s_final));
+    r->last_set = k;
     r->relative_frame_count += 1;                                    // lib.rs:1438-1439
     r->absolute_frame_count += 1;
     if (out_frame) *out_frame = r->absolute_frame_count;
@@ -229,7 +251,11 @@ int sr_renderer_render(SrRenderer* r, const float cam_pos[3], const float cam_ta
 int sr_renderer_wait_frame(SrRenderer* r, uint64_t frame) {
     if (!r) return rfail(SR_ERR_INVALID_ARG, "wait_frame: renderer is null");
     if (frame > r->absolute_frame_count) return rfail(SR_ERR_INVALID_ARG, "wait_frame: frame was never submitted");
-    R_HIP(hipEventSynchronize(r->frame_done));
+    if (frame + 1 >= r->absolute_frame_count && r->absolute_frame_count > 0) {
+        // the last submitted frame used image set last_set, the one before it the other set; older frames are long done
+        const int k = frame == r->absolute_frame_count ? r->last_set : (r->last_set ^ 1);
+        R_HIP(hipEventSynchronize(r->ev_done[k]));
+    }
     return SR_OK;
 }
 
@@ -245,7 +271,7 @@ int sr_renderer_render_to_host_memory(SrRenderer* r, const float cam_pos[3], con
         if (rc != SR_OK) return rc;
         if ((rc = sr_renderer_wait_frame(r, frame)) != SR_OK) return rc;
     }
-    R_HIP(hipMemcpy(out_rgba8, r->output, (size_t)r->width * r->height * 4, hipMemcpyDeviceToHost));
+    R_HIP(hipMemcpy(out_rgba8, r->output[r->last_set], (size_t)r->width * r->height * 4, hipMemcpyDeviceToHost));
     return SR_OK;
 }
 
@@ -374,8 +400,8 @@ int sr_renderer_unload_mesh(SrRenderer* r, uint64_t key) {
 int sr_renderer_get(SrRenderer* r, SrScene** scene, const uint32_t** output_rgba8_device, const float** raw_color_device, uint32_t* relative_frame_count) {
     if (!r) return rfail(SR_ERR_INVALID_ARG, "sr_renderer_get: renderer is null");
     if (scene) *scene = r->scene;
-    if (output_rgba8_device) *output_rgba8_device = r->output;
-    if (raw_color_device) *raw_color_device = r->raw_color;
+    if (output_rgba8_device) *output_rgba8_device = r->output[r->last_set];     // of the last submitted frame
+    if (raw_color_device) *raw_color_device = r->raw_color[r->last_set];
     if (relative_frame_count) *relative_frame_count = r->relative_frame_count;
     return SR_OK;
 }
