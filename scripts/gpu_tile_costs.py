@@ -22,3 +22,16 @@ for which, name, ms in ((0, "ris", a), (1, "final", b)):
     q = np.percentile(c, [50, 90, 99, 99.9, 100])
     print("%-5s kernel %.3f ms | wave duration us: mean %.0f median %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f | waves longer than half the kernel: %d of %d" % (
         name, ms, c.mean(), q[0], q[1], q[2], q[3], q[4], int((c > ms * 500).sum()), len(c)))
+# spatial profile: mean and max wave duration per band of 8 tile rows (64 pixel rows), final pass
+out = np.zeros(40000, dtype=np.uint32); n = C.c_uint32()
+check(lib().sr_scene_read_tile_costs(sc._h, 1, W, 0, H, out.ctypes.data_as(C.c_void_p), len(out), C.byref(n)))
+tiles_x, tiles_y = W // 8, H // 8
+grid = np.zeros((tiles_y, tiles_x))
+for xcd in range(8):
+    bx0, bx1 = (tiles_x * xcd) >> 3, (tiles_x * (xcd + 1)) >> 3
+    bw = bx1 - bx0
+    seg = out[bx0 * tiles_y: bx0 * tiles_y + bw * tiles_y].astype(np.float64) / 2100.0
+    grid[:, bx0:bx1] = seg.reshape(tiles_y, bw)
+for r0 in range(0, tiles_y, 9):
+    g = grid[r0:r0 + 9]
+    print("pixel rows %4d-%4d: mean %.0f us  max %.0f us" % (r0 * 8, min((r0 + 9) * 8, H) - 1, g.mean(), g.max()))
