@@ -483,9 +483,12 @@ int sr_renderer_load_mesh(SrRenderer* renderer, uint64_t key, const SrVertex* ve
                           const uint32_t* indices, uint32_t n_indices, const SrMaterial* material);
 /* Knobs for the ray-tracing passes (defaults = the reference's constants). */
 int sr_renderer_set_config(SrRenderer* renderer, const SrTraceConfig* config);
-/* Renderer::render(camera, instances) (lib.rs:984-1232): enqueues one whole frame on `stream`
- * (acceleration-structure rebuild if the instance list changed, raytracing_ris, raytracing_final,
- * temporal_accumulation, denoise_0..3, postprocess) and returns its frame number. */
+/* Renderer::render(camera, instances) (lib.rs:984-1232): enqueues one whole frame (acceleration-structure update /
+ * rebuild if the instance list changed, raytracing_ris, raytracing_final, temporal_accumulation, denoise_0..3,
+ * postprocess) on the renderer's OWN two streams, ordered after whatever is already enqueued on `stream`, and returns
+ * its frame number. Two frames may be in flight (MAX_FRAMES_IN_FLIGHT, lib.rs:71): per-frame images are double-buffered
+ * and the RIS pass of frame f+1 overlaps the final pass and post chain of frame f when the caller submits f+1 before
+ * waiting for f. Frames complete in order; results equal back-to-back execution. */
 int sr_renderer_render(SrRenderer* renderer, const float cam_pos[3], const float cam_target[3], float fov_y_degrees,
                        const uint64_t* keys, const uint32_t* counts, uint32_t n_keys, const SrTransform* transforms,
                        void* stream, uint64_t* out_frame);
@@ -534,8 +537,8 @@ int sr_loaded_scene_destroy(SrLoadedScene* loaded);
 int sr_renderer_unload_scene(SrRenderer* renderer, uint64_t group);
 int sr_renderer_unload_mesh(SrRenderer* renderer, uint64_t key);
 
-/* Harness access: inner scene (counters, stats), device pointers of the RGBA8 output and the fp32
- * radiance, and relative_frame_count. Any out pointer may be NULL. */
+/* Harness access: inner scene (counters, stats), device pointers of the RGBA8 output and the fp32 radiance OF THE LAST
+ * SUBMITTED FRAME (valid after sr_renderer_wait_frame of that frame), and relative_frame_count. Any out pointer may be NULL. */
 int sr_renderer_get(SrRenderer* renderer, SrScene** scene, const uint32_t** output_rgba8_device,
                     const float** raw_color_device, uint32_t* relative_frame_count);
 /* Stand-in for the reference's embedded 128x128 blue-noise PNG (lib.rs:281-309; an input asset, not
