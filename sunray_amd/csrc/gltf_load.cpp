@@ -497,6 +497,7 @@ struct GltfLoader {
                 if (n_nrm < n_pos) return fail("NORMAL shorter than POSITION");
                 const long tan_acc = attrs->index("TANGENT");
                 if (tan_acc >= 0) { if (!read_floats(tan_acc, 4, tangents, &n_tan)) return false; if (n_tan < n_pos) return fail("TANGENT shorter than POSITION"); }
+                if (n_pos == 0) return fail("primitive without vertices");
                 d.vertices.resize(n_pos);
                 memset(d.vertices.data(), 0, n_pos * sizeof(SrVertex));
                 for (size_t k = 0; k < n_pos; k++) {
