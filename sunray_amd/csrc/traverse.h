@@ -32,6 +32,9 @@ constexpr int kStackMax = 31;         // stack entries per lane the builders sha
                                       // Launches size the dynamic LDS stack to what the scene's tree actually needs.
 constexpr int kMaxBinaryDepth = 31;  // depth bound of the binary tree the 4-wide tree is collapsed from
 constexpr int kSentinel = 0x7fffffff;
+#ifndef SR_SPECULATIVE
+#define SR_SPECULATIVE 1   // speculative traversal (0: plain while-while, kept for A/B runs)
+#endif
 
 struct DevInstance {   // 96 B: (float3x3)WorldToObject3x4 in w2o[0..8], (float3x3)ObjectToWorld3x4 in o2w[0..8], row-major
     float w2o[12];
@@ -170,6 +173,11 @@ SRD int pick(int4 c, uint32_t i) {   // two levels of selects (v_cndmask), no br
     return (i & 2u) ? hi : lo;
 }
 
+SRD bool first_active_lane() {   // diagnostics only
+    const unsigned long long m = __ballot(1);
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u;
+}
+
 template <bool ANY, bool STATS>
 SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHit& hit, int* stack_base, int stride, TravStats& st) {
     const float4* __restrict__ nodes = sc.nodes;
@@ -185,7 +193,16 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
     hit.t = -1.0f; hit.u = 0.0f; hit.v = 0.0f; hit.gid = 0xFFFFFFFFu; hit.slot = 0u;
     int sp = 0;
     int node = 0;  // the root is always inner node 0
+#if SR_SPECULATIVE
+    int leaf = 0;  // postponed leaf reference (leaf references are negative; 0 = none)
+#endif
+#if SR_DIAG_UTIL == 2   // tuning diagnostics (variants only): lanes that enter a query vs 64 per wave-call
+    if (STATS) { st.boxes += 1; if (first_active_lane()) st.tris += 64; }
+#endif
     while (node != kSentinel) {
+#if SR_SPECULATIVE
+        bool searching = true;
+#endif
 #if SR_BVH_WIDTH == 8
         while (node >= 0 && node != kSentinel) {   // while-while: an if-if loop (one node of either kind per iteration) measured 5 % slower
             const float4* n = nodes + (size_t)node * (srl::kNodeDwords / 4);
@@ -239,13 +256,23 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
             stack_base[sp * stride] = cb.w; sp += (b7 && k7 != kmin) ? 1 : 0;
             const int lo4 = pick(ca, slot), hi4 = pick(cb, slot);
             node = (kmin != 0xFFFFFFFFu) ? ((slot & 4u) ? hi4 : lo4) : SR_POP();
+#if SR_SPECULATIVE
+            if (node < 0 && leaf == 0) { searching = false; leaf = node; node = SR_POP(); }
+            if (__ballot(searching) == 0ull) break;
+#endif
         }
 #else
         while (node >= 0 && node != kSentinel) {   // while-while: an if-if loop (one node of either kind per iteration) measured 5 % slower
             const float4* n = nodes + (size_t)node * 4;
             const float4 h0 = n[0], q1 = n[1], q2 = n[2], qc = n[3];
             const int4 child = make_int4(__float_as_int(qc.x), __float_as_int(qc.y), __float_as_int(qc.z), __float_as_int(qc.w));
+#if SR_DIAG_UTIL == 1       // tuning diagnostics: active lanes per node step vs 64 per wave-step (first active lane counts the wave)
+            if (STATS) { st.boxes += 1; if (first_active_lane()) st.tris += 64; }
+#elif SR_DIAG_UTIL == 3     // same for the triangle loop (below)
+#elif SR_DIAG_UTIL == 2
+#else
             if (STATS) st.boxes += 4;
+#endif
             const uint32_t ex = __float_as_uint(h0.w);
             const uint32_t LX = __float_as_uint(q1.x), LY = __float_as_uint(q1.y), LZ = __float_as_uint(q1.z);
             const uint32_t HX = __float_as_uint(q1.w), HY = __float_as_uint(q2.x), HZ = __float_as_uint(q2.y);
@@ -284,30 +311,54 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
             stack_base[sp * stride] = child.z; sp += (b2 && k2 != kmin) ? 1 : 0;
             stack_base[sp * stride] = child.w; sp += (b3 && k3 != kmin) ? 1 : 0;
             node = (kmin != 0xFFFFFFFFu) ? pick(child, slot) : SR_POP();
+#if SR_SPECULATIVE
+            // speculative traversal (Aila & Laine 2009): a lane that has reached its first leaf postpones it and keeps
+            // walking until every lane of the wave holds a leaf, so the triangle phase runs with fuller waves
+            if (node < 0 && leaf == 0) { searching = false; leaf = node; node = SR_POP(); }
+            if (__ballot(searching) == 0ull) break;
+#endif
         }
 #endif
+#if SR_SPECULATIVE
+        if (leaf == 0) break;   // nothing postponed: the walk ended on the sentinel
+        // Triangle phase, one triangle per lane and iteration: the postponed leaf first, then the leaf the walk stopped at
+        // (if any) and leaves popped after it. A leaf reference is ~(first << 3 | count): taking one triangle off its
+        // front is integer arithmetic, so lanes with short leaves move on to their next leaf instead of idling.
+        while (leaf != 0) {
+            const uint32_t lv = ~(uint32_t)leaf;
+            const uint32_t slot = lv >> 3, cnt = lv & 7u;
+            leaf = cnt > 1u ? (int)~(((slot + 1u) << 3) | (cnt - 1u)) : 0;
+            if (leaf == 0 && node < 0) { leaf = node; node = SR_POP(); }
+            if (cnt == 0u) continue;   // empty leaf (a builder's filler child; its box cannot be hit, kept for robustness)
+#else
         if (node == kSentinel) break;
-        // leaf
         const uint32_t lv = ~(uint32_t)node;
         const uint32_t first = lv >> 3, cnt = lv & 7u;
-        for (uint32_t i = 0; i < cnt; i++) {
-            const float4 t0 = tris[(size_t)(first + i) * 3 + 0];
-            const float4 t1 = tris[(size_t)(first + i) * 3 + 1];
-            const float4 t2 = tris[(size_t)(first + i) * 3 + 2];
+        for (uint32_t slot = first; slot < first + cnt; slot++) {
+#endif
+            const float4 t0 = tris[(size_t)slot * 3 + 0];
+            const float4 t1 = tris[(size_t)slot * 3 + 1];
+            const float4 t2 = tris[(size_t)slot * 3 + 2];
             float t, u, v;
+#if SR_DIAG_UTIL == 3
+            if (STATS) { st.boxes += 1; if (first_active_lane()) st.tris += 64; }
+#elif !SR_DIAG_UTIL
             if (STATS) st.tris += 1;
+#endif
             if (intersect_tri(o, d, mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), tmin, tmax, t, u, v)) {
                 if (ANY) return true;
                 const uint32_t gid = __float_as_uint(t2.y);
                 if (t < best_t || (t == best_t && gid < hit.gid)) {
                     best_t = t;
                     hit.t = t; hit.u = u; hit.v = v;
-                    hit.gid = gid; hit.slot = first + i;
+                    hit.gid = gid; hit.slot = slot;
                     cull = fmaf(fabsf(t), 1e-5f, t);
                 }
             }
         }
+#if !SR_SPECULATIVE
         node = SR_POP();
+#endif
     }
     if (STATS) {   // diagnostics: remember the most expensive ray of the launch
         const uint32_t steps = st.boxes - boxes_at_entry;
