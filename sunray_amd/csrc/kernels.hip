@@ -20,6 +20,13 @@ constexpr int kBlock = 256;        // ray-queue and shade kernels
 #endif
 constexpr int kPassBlock = SR_PASS_BLOCK;                 // the two pass megakernels: one wave = one 8x8 pixel tile
 constexpr int kPassTile = kPassBlock == 256 ? 16 : 8;     // (256 threads: 16x16 tile of four 8x8 wave tiles)
+#ifndef SR_WORK_STEALING
+#define SR_WORK_STEALING 1        // 1: lanes that finish their ray early take over subtrees of the wave's busy lanes (traverse_ws)
+#endif
+constexpr int kLdsExtraRows = (SR_WORK_STEALING && SR_BVH_WIDTH != 8) ? kWsRows : 0;
+#ifndef SR_FLAT_FINAL
+#define SR_FLAT_FINAL 1           // 1 (with SR_WORK_STEALING): predicated form of the final pass, all lanes reach every trace point
+#endif
 #ifndef SR_RIS_WAVES
 #define SR_RIS_WAVES 4
 #endif
@@ -52,17 +59,29 @@ __global__ __launch_bounds__(kBlock) void trace_queue_kernel(DevScene sc, const 
         base = __shfl(base, 0);
         if (base >= n) break;  // wave-uniform exit: every wave reaches it once the queue is drained
         const uint32_t i = base + lane;
+#if SR_WORK_STEALING && SR_BVH_WIDTH != 8
+        {
+            const uint32_t ic = i < n ? i : n - 1u;
+            const float4 ra = reinterpret_cast<const float4*>(rays)[ic * 2 + 0];
+            const float4 rb = reinterpret_cast<const float4*>(rays)[ic * 2 + 1];
+            TravHit h;
+            const bool found = traverse_ws<ANY, STATS>(sc, i < n, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), ra.w, rb.w, h, stack, kBlock, st);
+            if (i < n) {
+#else
         if (i < n) {
             const float4 ra = reinterpret_cast<const float4*>(rays)[i * 2 + 0];
             const float4 rb = reinterpret_cast<const float4*>(rays)[i * 2 + 1];
             TravHit h;
             const bool found = traverse<ANY, STATS>(sc, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), ra.w, rb.w, h, stack, kBlock, st);
+            {
+#endif
             n_queries++;
             if (ANY) occluded[i] = found ? 1u : 0u;
             else {
                 float4 o;
                 o.x = h.t; o.y = h.u; o.z = h.v; o.w = __uint_as_float(h.gid);
                 reinterpret_cast<float4*>(hits)[i] = o;
+            }
             }
         }
     }
@@ -115,7 +134,11 @@ struct PixelCtx {
 template <int V>
 SRD Payload trace_closest_shaded(PixelCtx& cx, f3 o, f3 d, float tmin, float tmax) {
     TravHit h;
+#if SR_WORK_STEALING && SR_BVH_WIDTH != 8
+    traverse_ws<false, (V & 1) != 0>(cx.a.sc, true, o, d, tmin, tmax, h, cx.stack, kPassBlock, cx.st);
+#else
     traverse<false, (V & 1) != 0>(cx.a.sc, o, d, tmin, tmax, h, cx.stack, kPassBlock, cx.st);
+#endif
     cx.n_closest++;
     return shade_hit<(V & 2) != 0>(cx.a.sc, h);
 }
@@ -126,7 +149,11 @@ SRD float trace_shadow(PixelCtx& cx, f3 o, f3 d, float dist) {
     if (dist > 0.002f) {
         TravHit h;
         cx.n_any++;
+#if SR_WORK_STEALING && SR_BVH_WIDTH != 8
+        return traverse_ws<true, (V & 1) != 0>(cx.a.sc, true, o, d, 0.001f, dist - 0.001f, h, cx.stack, kPassBlock, cx.st) ? 1.0f : -1.0f;
+#else
         return traverse<true, (V & 1) != 0>(cx.a.sc, o, d, 0.001f, dist - 0.001f, h, cx.stack, kPassBlock, cx.st) ? 1.0f : -1.0f;
+#endif
     }
     return -1.0f;
 }
@@ -244,6 +271,16 @@ __global__ void tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* _
         order[base + i] = (bottom_up ? tiles_y - 1u - r : r) * bw + x;
     }
 }
+
+#if SR_WORK_STEALING && SR_BVH_WIDTH != 8
+// One query of the flattened passes: reached by every lane of the wave, `want` = this lane has a ray (counted as the
+// TraceRay it stands for). Returns found / occluded for the lane's own ray.
+template <int V, bool ANY>
+SRD bool ws_query(PixelCtx& cx, bool want, f3 o, f3 d, float tmin, float tmax, TravHit& h) {
+    if (want) { if (ANY) cx.n_any++; else cx.n_closest++; }
+    return traverse_ws<ANY, (V & 1) != 0>(cx.a.sc, want, o, d, tmin, tmax, h, cx.stack, kPassBlock, cx.st);
+}
+#endif
 
 template <int V>
 __global__ __launch_bounds__(kPassBlock, SR_RIS_WAVES) void ris_kernel(const PassArgs a) {
@@ -487,7 +524,346 @@ __global__ __launch_bounds__(kPassBlock, SR_RIS_WAVES) void ris_kernel(const Pas
         if (V & 1) { flush_counter(sc.counters + 2, counted ? cx.st.boxes : 0u); flush_counter(sc.counters + 3, counted ? cx.st.tris : 0u); }
     }
 }
+#if SR_WORK_STEALING && SR_BVH_WIDTH != 8 && SR_FLAT_FINAL
+template <int V>
+__global__ __launch_bounds__(kPassBlock, SR_FINAL_WAVES) void final_kernel(const PassArgs a) {
+    // Flattened form of the pass for the work-stealing traversal: every trace point is reached by ALL lanes of the wave
+    // (the control flow around it is predicated, not branched), so lanes without a ray of their own can take over
+    // subtrees of the lanes that have one. Same operations in the same order per pixel as the branched form.
+    extern __shared__ __attribute__((aligned(16))) int s_stack[];
+    PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
+    const DevScene& sc = a.sc;
+    uint32_t px = 0, py = 0, cost_slot = 0;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    const bool active = thread_pixel(a, px, py, cost_slot);
+    const uint32_t W = a.width, H = a.height;
+    const uint32_t pix = active ? py * W + px : 0u;
+    const int ipx = (int)px, ipy = (int)py;
+    const uint32_t cur_buf = a.frame_count & 1u;
+    const SrReservoir* reservoir_cur = a.reservoirs[cur_buf];
+    const SrReservoirGI* reservoir_gi_cur = a.reservoirs_gi[cur_buf];
+    const uint32_t num_lights = sc.num_lights;
 
+    uint32_t rng = init_rng(px, py, a.frame_count, W);                                 // :37
+    const int BOUNCES = (int)a.cfg.max_bounces;
+    const int SHADOW_BOUNCES = (int)a.cfg.shadow_bounces;
+    float bn_1 = 0.0f, bn_2 = 0.0f;
+    if (active) {                                                                      // :44-50
+        const int bw = (int)a.blue_noise_w, bh = (int)a.blue_noise_h;
+        const int n1x = ipx % bw, n1y = ipy % bh;
+        const int n2x = (ipx + 47) % bw, n2y = (ipy + 71) % bh;
+        bn_1 = (float)a.blue_noise_tex[((size_t)n1y * bw + n1x) * 4] / 255.0f;
+        bn_2 = (float)a.blue_noise_tex[((size_t)n2y * bw + n2x) * 4] / 255.0f;
+    }
+    f3 origin, rayDir0; f2 inUV;
+    primary_ray(a.mats, px, py, W, H, origin, rayDir0, inUV);                          // :58-67
+    f3 rayOrigin = origin, rayDir = rayDir0;
+    f3 throughput = splat(1.0f), radiance = splat(0.0f);
+    bool restir_evaluated = (a.cfg.enable_restir == 0);
+    bool prev_did_nee = false;
+    Payload prd;
+    TravHit h; bool occ;
+
+    bool in_loop = active;
+    for (int bounce = 0; bounce < BOUNCES; bounce++) {                                 // :74
+        if (__ballot(in_loop) == 0ull) break;
+        ws_query<V, false>(cx, in_loop, rayOrigin, rayDir, 0.001f, 10000.0f, h);
+        bool do_restir = false, do_nee = false, do_bounce = false;
+        f3 hit_normal = splat(0.0f), hit_albedo = splat(0.0f), hitPos = splat(0.0f), V_view = splat(0.0f);
+        float roughness = 0.5f, metallic = 0.0f;
+        if (in_loop) {
+            prd = shade_hit<(V & 2) != 0>(sc, h);
+            if (prd.dist < 0.0f) in_loop = false;                                      // :82-84
+            else {
+                hit_normal = unpack_normal(prd.normal_packed);
+                hit_albedo = unpack_unorm_rgb(prd.albedo_packed);
+                hitPos = rayOrigin + rayDir * prd.dist;
+                V_view = -rayDir;
+                const f2 mat_info = unpack_half_2x16(prd.material_info);
+                roughness = fmaxf(mat_info.x, 0.01f);
+                metallic = clampf(mat_info.y, 0.0f, 1.0f);
+                const f2 trans_ior = unpack_half_2x16(prd.transmission_ior_packed);
+                const float transmission = trans_ior.x;
+                const float ior = fmaxf(trans_ior.y, 1.0f);
+                if (!prev_did_nee) radiance = radiance + prd.emission * throughput;    // :99-101
+                prev_did_nee = false;
+                const float brightness = maxc(prd.emission);
+                if (brightness > 1.0f) in_loop = false;                                // :104
+                else if (transmission > 0.5f) {                                        // :106-133 (continue)
+                    const bool is_inside = dot3(rayDir, hit_normal) > 0.0f;
+                    const f3 N = is_inside ? -hit_normal : hit_normal;
+                    const float eta = is_inside ? (ior / 1.0f) : (1.0f / ior);
+                    const float cos_theta = fminf(dot3(-rayDir, N), 1.0f);
+                    float R0 = (1.0f - eta) / (1.0f + eta);
+                    R0 = R0 * R0;
+                    float fresnel = R0 + (1.0f - R0) * pow5f(1.0f - cos_theta);
+                    const f3 refracted = refract3(rayDir, N, eta);
+                    if (len3(refracted) < 0.01f) fresnel = 1.0f;
+                    if (rnd(rng) < fresnel) rayDir = reflect3(rayDir, N);
+                    else {
+                        rayDir = refracted;
+                        if (is_inside) {
+                            const f3 absorption = 1.0f - hit_albedo;
+                            const f3 e = -absorption * prd.dist * 5.0f;
+                            throughput = throughput * mk3(exp_pinned(e.x), exp_pinned(e.y), exp_pinned(e.z));
+                        } else throughput = throughput * hit_albedo;
+                    }
+                    rayOrigin = hitPos + rayDir * 0.001f;
+                } else {
+                    do_bounce = true;
+                    if (num_lights > 0 && bounce < SHADOW_BOUNCES) {                   // :135
+                        if (!restir_evaluated && roughness > 0.2f) { restir_evaluated = true; do_restir = true; do_bounce = false; }
+                        else if (restir_evaluated && roughness > 0.2f) do_nee = true;
+                    }
+                }
+            }
+        }
+
+        // ---- :136-327 first rough hit: ReSTIR DI + GI spatial reuse, then the walk stops ----
+        if (__ballot(do_restir) != 0ull) {
+            SrReservoir spatial_r; zero_reservoir(spatial_r);
+            f3 f_y_winner = splat(0.0f), shadow_dir = splat(0.0f);
+            float shadow_dist = 0.0f;
+            bool di_pending = false, want_di = false;
+            if (do_restir) {
+                SrReservoir center_r = load48(reservoir_cur + pix);                    // :139-158
+                if (center_r.W > 0.0f && center_r.light_idx < num_lights) {
+                    center_r.light_idx = center_r.light_idx < num_lights - 1 ? center_r.light_idx : num_lights - 1;
+                    const f3 fc = eval_unshadowed_light(hitPos, hit_normal, V_view, hit_albedo, roughness, metallic,
+                                                        light_emission(sc, center_r.light_idx), ld3(center_r.light_pos), ld3(center_r.light_normal));
+                    const float cr = rnd(rng);
+                    merge_reservoirs(spatial_r, center_r, maxc(fc), cr);
+                }
+                const float current_depth = len3(hitPos - origin);                     // :162
+                for (int s = 0; s < 5; s++) {                                          // :164-188 SPATIAL_SAMPLES = 5, RADIUS = 30
+                    const float angle = rnd(rng) * 2.0f * 3.14159f;
+                    const float radius = sqrtf(rnd(rng)) * 30.0f;
+                    float sa, ca; sincos_pinned(angle, sa, ca);
+                    const int ncx = ipx + (int)(ca * radius), ncy = ipy + (int)(sa * radius);
+                    if (ncx < 0 || ncy < 0 || ncx >= (int)W || ncy >= (int)H) continue;
+                    const uint32_t pi_n = (uint32_t)ncy * W + (uint32_t)ncx;
+                    const f3 neighbor_normal = load_normal(a, pi_n);
+                    const float neighbor_depth = load_depth(a, pi_n);
+                    if (dot3(hit_normal, neighbor_normal) < 0.9f) continue;
+                    if (fabsf(current_depth - neighbor_depth) > 0.1f * current_depth) continue;
+                    SrReservoir nr = load48(reservoir_cur + pi_n);
+                    nr.W = fminf(nr.W, 20.0f);
+                    nr.M = fminf(nr.M, 10.0f);
+                    if (nr.W > 0.0f && nr.light_idx < num_lights) {
+                        nr.light_idx = nr.light_idx < num_lights - 1 ? nr.light_idx : num_lights - 1;
+                        const f3 fn = eval_unshadowed_light(hitPos, hit_normal, V_view, hit_albedo, roughness, metallic,
+                                                            light_emission(sc, nr.light_idx), ld3(nr.light_pos), ld3(nr.light_normal));
+                        const float nrnd = rnd(rng);
+                        merge_reservoirs(spatial_r, nr, maxc(fn), nrnd);
+                    }
+                }
+                if (spatial_r.w_sum > 0.0f) {                                          // :190-205
+                    f_y_winner = eval_unshadowed_light(hitPos, hit_normal, V_view, hit_albedo, roughness, metallic,
+                                                       light_emission(sc, spatial_r.light_idx), ld3(spatial_r.light_pos), ld3(spatial_r.light_normal));
+                    spatial_r.W = spatial_r.w_sum / fmaxf(spatial_r.M * maxc(f_y_winner), 1e-3f);
+                    spatial_r.W = fminf(spatial_r.W, 50.0f);
+                    shadow_dir = ld3(spatial_r.light_pos) - hitPos;
+                    shadow_dist = fmaxf(len3(shadow_dir), 0.0001f);
+                    shadow_dir = shadow_dir / shadow_dist;
+                    if (dot3(hit_normal, shadow_dir) > 0.0f) { di_pending = true; want_di = shadow_dist > 0.002f; }
+                }
+            }
+            occ = ws_query<V, true>(cx, want_di, hitPos, shadow_dir, 0.001f, shadow_dist - 0.001f, h);   // :206-212 (origin = bare hitPos)
+            if (di_pending) {
+                prd.dist = want_di ? (occ ? 1.0f : -1.0f) : -1.0f;
+                if (prd.dist < 0.0f) radiance = radiance + f_y_winner * throughput * spatial_r.W;             // :217-219
+                prev_did_nee = true;
+            }
+
+            // ReSTIR GI spatial reuse (:224-291)
+            SrReservoirGI combined; zero_reservoir_gi(combined);
+            float gi_current_depth = 0.0f;
+            if (do_restir) {
+                combined = load48(reservoir_gi_cur + pix);
+                gi_current_depth = len3(hitPos - origin);
+            }
+            for (int s = 0; s < 3; s++) {                                              // GI_SPATIAL_SAMPLES = 3, RADIUS = 20
+                bool cand = false, want_g = false;
+                SrReservoirGI nr; zero_reservoir_gi(nr);
+                float jacobian = 0.0f, d_new = 0.0f;
+                f3 gi_spatial_dir = splat(0.0f), nsp = splat(0.0f);
+                if (do_restir) {
+                    const float gi_angle = rnd(rng) * 2.0f * 3.14159f;
+                    const float gi_radius = sqrtf(rnd(rng)) * 20.0f;
+                    float sa, ca; sincos_pinned(gi_angle, sa, ca);
+                    const int ncx = ipx + (int)(ca * gi_radius), ncy = ipy + (int)(sa * gi_radius);
+                    bool ok = !(ncx == ipx && ncy == ipy);                             // :237
+                    ok = ok && !(ncx < 0 || ncy < 0 || ncx >= (int)W || ncy >= (int)H);
+                    if (ok) {
+                        const uint32_t pi_nn = (uint32_t)ncy * W + (uint32_t)ncx;
+                        const f3 neighbor_normal = load_normal(a, pi_nn);
+                        const float neighbor_depth = load_depth(a, pi_nn);
+                        ok = !(dot3(hit_normal, neighbor_normal) < 0.9f);
+                        ok = ok && !(fabsf(gi_current_depth - neighbor_depth) > 0.1f * gi_current_depth);
+                        if (ok) {
+                            nr = load48(reservoir_gi_cur + pi_nn);
+                            ok = !(nr.W <= 0.0f);                                      // :248
+                            if (ok) {
+                                nr.W = fminf(nr.W, 10.0f);
+                                nr.M = fminf(nr.M, 10.0f);
+                                f3 n_origin, n_dir; f2 n_uv;
+                                primary_ray(a.mats, (uint32_t)ncx, (uint32_t)ncy, W, H, n_origin, n_dir, n_uv);   // :253-258
+                                const f3 neighbor_x1 = origin + n_dir * neighbor_depth;
+                                nsp = ld3(nr.sample_pos);
+                                const f3 w_new = nsp - hitPos;
+                                const f3 w_old = nsp - neighbor_x1;
+                                d_new = fmaxf(len3(w_new), 1e-4f);
+                                const float d_old = fmaxf(len3(w_old), 1e-4f);
+                                const f3 n_x2 = unpack_normal(nr.sample_normal_packed);
+                                const float cos_new = fmaxf(dot3(n_x2, (-w_new) / d_new), 0.0f);
+                                const float cos_old = fmaxf(dot3(n_x2, (-w_old) / d_old), 0.0f);
+                                ok = !(cos_new <= 0.0f || cos_old <= 0.0f);            // :267
+                                if (ok) {
+                                    jacobian = (cos_new * d_old * d_old) / fmaxf(cos_old * d_new * d_new, 1e-4f);
+                                    jacobian = clampf(jacobian, 0.0f, 10.0f);
+                                    gi_spatial_dir = w_new / d_new;
+                                    ok = !(dot3(hit_normal, gi_spatial_dir) <= 0.0f);  // :273
+                                    if (ok) { cand = true; want_g = d_new > 0.002f; }
+                                }
+                            }
+                        }
+                    }
+                }
+                occ = ws_query<V, true>(cx, want_g, hitPos, gi_spatial_dir, 0.001f, d_new - 0.001f, h);   // :276-286
+                if (cand) {
+                    prd.dist = want_g ? (occ ? 1.0f : -1.0f) : -1.0f;
+                    if (!(prd.dist >= 0.0f)) {                                         // :287
+                        const float p_hat_neighbor = gi_target_pdf(hitPos, hit_normal, hit_albedo, metallic, nsp, ld3(nr.sample_radiance));
+                        const float gr = rnd(rng);
+                        merge_reservoirs_gi(combined, nr, p_hat_neighbor, jacobian, gr);
+                    }
+                }
+            }
+            bool gif_pending = false, want_gif = false;
+            f3 gi_x2_dir = splat(0.0f);
+            float gi_x2_dist = 0.0f, gi_NdotL = 0.0f;
+            if (do_restir) {                                                           // :293-303
+                const float p_hat_final = gi_target_pdf(hitPos, hit_normal, hit_albedo, metallic, ld3(combined.sample_pos), ld3(combined.sample_radiance));
+                combined.W = (p_hat_final > 1e-3f) ? (combined.w_sum / fmaxf(combined.M, 1.0f) / p_hat_final) : 0.0f;
+                combined.W = fminf(combined.W, 20.0f);
+                if (combined.W > 0.0f) {
+                    gi_x2_dir = ld3(combined.sample_pos) - hitPos;
+                    gi_x2_dist = fmaxf(len3(gi_x2_dir), 0.0001f);
+                    gi_x2_dir = gi_x2_dir / gi_x2_dist;
+                    gi_NdotL = fmaxf(dot3(hit_normal, gi_x2_dir), 0.0f);
+                    if (gi_NdotL > 0.0f) { gif_pending = true; want_gif = gi_x2_dist > 0.002f; }
+                }
+            }
+            occ = ws_query<V, true>(cx, want_gif, hitPos, gi_x2_dir, 0.001f, gi_x2_dist - 0.001f, h);   // :309-316
+            if (gif_pending) {
+                prd.dist = want_gif ? (occ ? 1.0f : -1.0f) : -1.0f;
+                if (prd.dist < 0.0f) {                                                 // :321-324
+                    const f3 gi_f_diffuse = hit_albedo * (1.0f - metallic) / 3.14159f;
+                    radiance = radiance + ld3(combined.sample_radiance) * gi_f_diffuse * gi_NdotL * combined.W * throughput;
+                }
+            }
+            if (do_restir) in_loop = false;                                            // :327 break
+        }
+
+        // ---- :328-382 later rough bounces: one NEE sample ----
+        if (__ballot(do_nee) != 0ull) {
+            bool nee_pending = false, want_nee = false;
+            f3 shadow_ray_dir = splat(0.0f), nee_emission = splat(0.0f);
+            float light_dist = 0.0f, cos_theta_light = 0.0f, cos_theta_surface = 0.0f, light_area = 0.0f;
+            if (do_nee) {
+                uint32_t light_idx = (uint32_t)(rnd(rng) * (float)num_lights);
+                if (light_idx > num_lights - 1) light_idx = num_lights - 1;
+                const LightTri lt = fetch_light(sc, light_idx);
+                light_area = lt.area;
+                nee_emission = lt.emission;
+                const float r1_nee = rnd(rng);
+                const float r2_nee = rnd(rng);
+                const float sqr1 = sqrtf(r1_nee);
+                const float u = 1.0f - sqr1;
+                const float v = r2_nee * sqr1;
+                const float w = 1.0f - u - v;
+                const f3 light_pos = lt.wv0 * u + lt.wv1 * v + lt.wv2 * w;
+                const f3 light_normal = lt.normal;
+                shadow_ray_dir = light_pos - hitPos;
+                light_dist = len3(shadow_ray_dir);
+                shadow_ray_dir = shadow_ray_dir / light_dist;
+                cos_theta_light = fmaxf(dot3(light_normal, -shadow_ray_dir), 0.0f);
+                cos_theta_surface = fmaxf(dot3(hit_normal, shadow_ray_dir), 0.0f);
+                if (cos_theta_light > 0.0f && cos_theta_surface > 0.0f) { nee_pending = true; want_nee = light_dist > 0.002f; }
+            }
+            occ = ws_query<V, true>(cx, want_nee, hitPos, shadow_ray_dir, 0.001f, light_dist - 0.001f, h);   // :363-370
+            if (nee_pending) {
+                prd.dist = want_nee ? (occ ? 1.0f : -1.0f) : -1.0f;
+                if (prd.dist < 0.0f) {                                                 // :375-379
+                    const float solid_angle_pdf = (light_dist * light_dist) / fmaxf(cos_theta_light * light_area * (float)num_lights, 1e-4f);
+                    const f3 nee_contrib = (nee_emission * hit_albedo * throughput * cos_theta_surface) / (solid_angle_pdf * 3.14159f);
+                    radiance = radiance + vmin(nee_contrib, splat(5.0f));
+                }
+                prev_did_nee = true;
+            }
+        }
+
+        // ---- :385-427 BRDF bounce ----
+        if (in_loop && do_bounce) {
+            const f3 N = hit_normal;
+            const f3 F0 = lerp3(splat(0.04f), hit_albedo, metallic);
+            const float cos_theta = fmaxf(dot3(N, V_view), 0.0f);
+            const f3 F = F0 + (1.0f - F0) * pow5f(clampf(1.0f - cos_theta, 0.0f, 1.0f));
+            const float p_specular = clampf(maxc(F), 0.05f, 1.0f);
+            float r1, r2;
+            if (bounce == 0) {
+                r1 = fracf(bn_1 + (float)(a.frame_count % 1024u) * 0.75487766f);
+                r2 = fracf(bn_2 + (float)(a.frame_count % 1024u) * 0.56984029f);
+            } else {
+                r1 = rnd(rng);
+                r2 = rnd(rng);
+            }
+            if (rnd(rng) < p_specular) {
+                const f3 Hh = sample_ggx_vndf(N, V_view, roughness, r1, r2);
+                rayDir = reflect3(-V_view, Hh);
+                if (dot3(N, rayDir) <= 0.0f) {
+                    rayDir = get_random_bounce(N, r1, r2);
+                    throughput = throughput * (hit_albedo * (1.0f - metallic) * (1.0f - F) / (1.0f - p_specular));
+                } else {
+                    const float NdotL_b = fmaxf(dot3(N, rayDir), 0.001f);
+                    const float alpha_b = roughness * roughness;
+                    const float G1_L = smith_g1_ggx(NdotL_b, alpha_b);
+                    throughput = throughput * ((F * G1_L) / p_specular);
+                }
+            } else {
+                rayDir = get_random_bounce(N, r1, r2);
+                throughput = throughput * (hit_albedo * (1.0f - metallic) * (1.0f - F) / (1.0f - p_specular));
+            }
+            const float p = maxc(throughput);
+            if (p < 0.001f) in_loop = false;                                           // :420
+            else {
+                bool cont = true;
+                if (bounce > 2) {
+                    if (rnd(rng) > p) cont = false;                                    // :423
+                    else throughput = throughput / p;
+                }
+                if (cont) rayOrigin = hitPos + hit_normal * 0.001f;                    // :427
+                else in_loop = false;
+            }
+        }
+    }
+    if (active) {                                                                      // :430-435
+        f3 total_radiance = splat(0.0f) + radiance;
+        total_radiance = vmin(total_radiance, splat(10.0f));
+        const f3 color = total_radiance / 1.0f;  // / float(SAMPLES)
+        float4 o;
+        o.x = color.x; o.y = color.y; o.z = color.z; o.w = 1.0f;
+        reinterpret_cast<float4*>(a.raw_color)[pix] = o;
+    }
+    record_tile_cost(a, cost_slot, t_start);
+    if (!(a.cfg.flags & SR_TRACE_FLAG_UNCOUNTED)) {
+        const bool counted = a.cfg.count_rows == 0u || (py - a.cfg.count_y0) < a.cfg.count_rows;   // per lane: its pixel's row
+        flush_counter(sc.counters + 0, counted ? cx.n_closest : 0u);
+        flush_counter(sc.counters + 1, counted ? cx.n_any : 0u);
+        if (V & 1) { flush_counter(sc.counters + 2, counted ? cx.st.boxes : 0u); flush_counter(sc.counters + 3, counted ? cx.st.tris : 0u); }
+    }
+}
+#else
 template <int V>
 __global__ __launch_bounds__(kPassBlock, SR_FINAL_WAVES) void final_kernel(const PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kPassBlock], sized at launch
@@ -756,6 +1132,7 @@ __global__ __launch_bounds__(kPassBlock, SR_FINAL_WAVES) void final_kernel(const
         if (V & 1) { flush_counter(sc.counters + 2, counted ? cx.st.boxes : 0u); flush_counter(sc.counters + 3, counted ? cx.st.tris : 0u); }
     }
 }
+#endif
 
 }  // namespace srd
 
@@ -770,7 +1147,7 @@ int srk_launch_trace(const DevScene& sc, const SrRay* rays, uint32_t n, SrHit* h
     if (e != hipSuccess) return (int)e;
     if (n == 0) return 0;
     dim3 grid(n_blocks), block(kBlock);
-    const size_t lds = (size_t)stack_entries * kBlock * sizeof(int);
+    const size_t lds = (size_t)(stack_entries + kLdsExtraRows) * kBlock * sizeof(int);
     if (any) {
         if (stats) trace_queue_kernel<true, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head);
         else trace_queue_kernel<true, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head);
@@ -797,7 +1174,7 @@ int srk_launch_pass(const PassArgs& args_in, int which, int stats, int textured,
     const uint32_t n_tiles = args.tiles_x * args.tiles_y;
     if (n_tiles == 0) return 0;
     dim3 grid(args.tiles_per_xcd * 8), block(kPassBlock);
-    const size_t lds = (size_t)stack_entries * kPassBlock * sizeof(int);
+    const size_t lds = (size_t)(stack_entries + kLdsExtraRows) * kPassBlock * sizeof(int);
     const int v = (stats ? 1 : 0) | (textured ? 2 : 0);
     if (which == 0) {
         switch (v) {

@@ -372,6 +372,173 @@ SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHi
     return hit.gid != 0xFFFFFFFFu;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Work-stealing traversal (4-wide trees). Rays of one wave differ a lot in length: measured on the bench frame, the
+// lanes that enter a query together are busy for only half of the wave's node steps, the rest have finished and wait
+// for the longest ray. Here a lane that runs out of work takes the BOTTOM entry of a busy lane's stack (the stacks
+// live in LDS, one column per lane, so any lane of the wave can read them) together with that lane's ray, and walks
+// the subtree on its own stack. Results meet in LDS: per ray one 64-bit key (ordered t, triangle id) updated with an
+// atomic minimum — exactly the tie rule of the sequential walk (smallest t, then lowest id), so the answer does not
+// depend on who found it — and the payload (t, u, v, slot) written by whoever holds the minimum. The key also carries
+// the best t to every lane working for the ray (culling bound) and, for existence queries, the "found" flag.
+// Box culling is conservative, so splitting a walk cannot change its result.
+// LDS: kWsRows rows of `stride` ints in front of the stack levels: keys (2 rows), lane exchange (1), payload (4).
+// ---------------------------------------------------------------------------------------------
+constexpr int kWsRows = 7;
+SRD uint32_t ord_f32(float f) { const uint32_t b = __float_as_uint(f + 0.0f); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+SRD float unord_f32(uint32_t k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+SRD uint32_t lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
+#define SR_WS_POP() (sp == sb ? kSentinel : stack_base[(--sp) * stride])
+
+// Every lane of the wave that is active at the call site takes part; `want` = this lane has a ray of its own.
+template <bool ANY, bool STATS>
+SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, float tmax, TravHit& hit, int* lds_col, int stride, TravStats& st) {
+    const float4* __restrict__ nodes = sc.nodes;
+    const float4* __restrict__ tris = sc.tris;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    int* const blk = lds_col - tid;
+    unsigned long long* const keys = reinterpret_cast<unsigned long long*>(blk);   // rows 0-1: one u64 per thread
+    int* const xch = blk + 2 * stride + (tid & ~63u);                               // row 2: this wave's 64 exchange slots
+    int* const pay = blk + 3 * stride;                                              // rows 3-6: t, u, v, slot of the key holder
+    int* const stack_base = lds_col + kWsRows * stride;
+    keys[tid] = ~0ull;
+    uint32_t root = tid;                 // thread whose ray this lane is working for
+    RaySetup rs = ray_setup(o, d);
+    float t_lo = fminf(tmin, 0.0f) - fabsf(tmin);
+    float cull = fmaf(fabsf(tmax), 1e-5f, tmax);
+    float best_t = tmax;
+    uint32_t best_gid = 0xFFFFFFFFu;
+    int sp = 0, sb = 0, leaf = 0;
+    int node = want ? 0 : kSentinel;
+    for (;;) {
+        // ---- phase top: all participating lanes meet here ----
+        if (node != kSentinel) {
+            const unsigned long long k = keys[root];
+            if (ANY) { if (k == 0ull) { node = kSentinel; sp = sb; } }        // somebody found an occluder
+            else if (k != ~0ull) { const float ts = unord_f32((uint32_t)(k >> 32)); cull = fminf(cull, fmaf(fabsf(ts), 1e-5f, ts)); }
+        }
+        if (__ballot(node != kSentinel) == 0ull) break;
+        // ---- node phase: wave-uniform loop, so that lanes without work stay in step and can be handed some ----
+        for (;;) {
+            const bool inner = node >= 0 && node != kSentinel;
+            if (__ballot(inner && leaf == 0) == 0ull) break;   // every walking lane holds a (postponed) leaf: on to the triangles
+            const bool idle = node == kSentinel && leaf == 0;
+            const unsigned long long idle_mask = __ballot(idle);
+            if (idle_mask != 0ull) {
+                const bool can_give = inner && sp > sb;
+                const unsigned long long donor_mask = __ballot(can_give);
+                if (donor_mask != 0ull) {
+                    const uint32_t n = min((uint32_t)__popcll(idle_mask), (uint32_t)__popcll(donor_mask));
+                    const uint32_t drank = lanes_below(donor_mask), irank = lanes_below(idle_mask);
+                    const bool gives = can_give && drank < n, takes = idle && irank < n;
+                    if (gives) xch[drank] = (int)lane;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    const int dl = takes ? xch[irank] : (int)lane;
+                    const int d_sb = __shfl(sb, dl);
+                    const uint32_t d_root = (uint32_t)__shfl((int)root, dl);
+                    const float ox = __shfl(o.x, dl), oy = __shfl(o.y, dl), oz = __shfl(o.z, dl);
+                    const float dx = __shfl(d.x, dl), dy = __shfl(d.y, dl), dz = __shfl(d.z, dl);
+                    const float d_tmin = __shfl(tmin, dl), d_tmax = __shfl(tmax, dl), d_cull = __shfl(cull, dl);
+                    if (takes) {
+                        node = stack_base[d_sb * stride + (dl - (int)lane)];
+                        o = mk3(ox, oy, oz); d = mk3(dx, dy, dz); tmin = d_tmin; tmax = d_tmax; cull = d_cull; root = d_root;
+                        rs = ray_setup(o, d);
+                        t_lo = fminf(tmin, 0.0f) - fabsf(tmin);
+                        best_t = tmax; best_gid = 0xFFFFFFFFu;
+                        sp = 0; sb = 0;
+                        if (node < 0) { leaf = node; node = kSentinel; }   // the stolen entry is a leaf: it waits for the triangle phase
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    if (gives) sb++;
+                }
+            }
+            if (node >= 0 && node != kSentinel) {
+                const float4* n = nodes + (size_t)node * 4;
+                const float4 h0 = n[0], q1 = n[1], q2 = n[2], qc = n[3];
+                const int4 child = make_int4(__float_as_int(qc.x), __float_as_int(qc.y), __float_as_int(qc.z), __float_as_int(qc.w));
+#if SR_DIAG_UTIL == 1
+                if (STATS) { st.boxes += 1; if (first_active_lane()) st.tris += 64; }
+#elif !SR_DIAG_UTIL
+                if (STATS) st.boxes += 4;
+#endif
+                const uint32_t ex = __float_as_uint(h0.w);
+                const uint32_t LX = __float_as_uint(q1.x), LY = __float_as_uint(q1.y), LZ = __float_as_uint(q1.z);
+                const uint32_t HX = __float_as_uint(q1.w), HY = __float_as_uint(q2.x), HZ = __float_as_uint(q2.y);
+                NodePlanes p;
+                p.nx = rs.sx ? HX : LX; p.fx = rs.sx ? LX : HX;
+                p.ny = rs.sy ? HY : LY; p.fy = rs.sy ? LY : HY;
+                p.nz = rs.sz ? HZ : LZ; p.fz = rs.sz ? LZ : HZ;
+                p.ax = __uint_as_float((ex & 0xFFu) << 23) * rs.inv.x; p.ay = __uint_as_float(((ex >> 8) & 0xFFu) << 23) * rs.inv.y;
+                p.az = __uint_as_float(((ex >> 16) & 0xFFu) << 23) * rs.inv.z;
+                p.bx = (h0.x - rs.o.x) * rs.inv.x; p.by = (h0.y - rs.o.y) * rs.inv.y; p.bz = (h0.z - rs.o.z) * rs.inv.z;
+                float n0, n1, n2, n3;
+                const bool b0 = child_hit<0>(p, t_lo, cull, n0);
+                const bool b1 = child_hit<1>(p, t_lo, cull, n1);
+                const bool b2 = child_hit<2>(p, t_lo, cull, n2);
+                const bool b3 = child_hit<3>(p, t_lo, cull, n3);
+                uint32_t k0, k1, k2, k3;
+                if (ANY) {
+                    k0 = b0 ? 0u : 0xFFFFFFFFu; k1 = b1 ? 1u : 0xFFFFFFFFu; k2 = b2 ? 2u : 0xFFFFFFFFu; k3 = b3 ? 3u : 0xFFFFFFFFu;
+                } else {
+                    k0 = b0 ? ((__float_as_uint(fmaxf(n0, 0.0f)) & ~3u) | 0u) : 0xFFFFFFFFu;
+                    k1 = b1 ? ((__float_as_uint(fmaxf(n1, 0.0f)) & ~3u) | 1u) : 0xFFFFFFFFu;
+                    k2 = b2 ? ((__float_as_uint(fmaxf(n2, 0.0f)) & ~3u) | 2u) : 0xFFFFFFFFu;
+                    k3 = b3 ? ((__float_as_uint(fmaxf(n3, 0.0f)) & ~3u) | 3u) : 0xFFFFFFFFu;
+                }
+                const uint32_t kmin = min(min(k0, k1), min(k2, k3));
+                const uint32_t slot = kmin & 3u;
+                stack_base[sp * stride] = child.x; sp += (b0 && k0 != kmin) ? 1 : 0;
+                stack_base[sp * stride] = child.y; sp += (b1 && k1 != kmin) ? 1 : 0;
+                stack_base[sp * stride] = child.z; sp += (b2 && k2 != kmin) ? 1 : 0;
+                stack_base[sp * stride] = child.w; sp += (b3 && k3 != kmin) ? 1 : 0;
+                node = (kmin != 0xFFFFFFFFu) ? pick(child, slot) : SR_WS_POP();
+                if (node < 0 && leaf == 0) { leaf = node; node = SR_WS_POP(); }
+            }
+        }
+        while (leaf != 0) {
+            const uint32_t lv = ~(uint32_t)leaf;
+            const uint32_t slot = lv >> 3, cnt = lv & 7u;
+            leaf = cnt > 1u ? (int)~(((slot + 1u) << 3) | (cnt - 1u)) : 0;
+            if (leaf == 0 && node < 0) { leaf = node; node = SR_WS_POP(); }
+            if (cnt == 0u) continue;
+            const float4 t0 = tris[(size_t)slot * 3 + 0];
+            const float4 t1 = tris[(size_t)slot * 3 + 1];
+            const float4 t2 = tris[(size_t)slot * 3 + 2];
+            float t, u, v;
+#if SR_DIAG_UTIL == 3
+            if (STATS) { st.boxes += 1; if (first_active_lane()) st.tris += 64; }
+#elif !SR_DIAG_UTIL
+            if (STATS) st.tris += 1;
+#endif
+            if (intersect_tri(o, d, mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), tmin, tmax, t, u, v)) {
+                if (ANY) { keys[root] = 0ull; node = kSentinel; sp = sb; leaf = 0; break; }
+                const uint32_t gid = __float_as_uint(t2.y);
+                if (t < best_t || (t == best_t && gid < best_gid)) {
+                    best_t = t; best_gid = gid;
+                    cull = fminf(cull, fmaf(fabsf(t), 1e-5f, t));
+                    const unsigned long long key = ((unsigned long long)ord_f32(t) << 32) | gid;
+                    atomicMin(&keys[root], key);
+                    if (keys[root] == key) {   // this lane holds the minimum: its payload stands
+                        pay[0 * stride + root] = __float_as_int(t); pay[1 * stride + root] = __float_as_int(u);
+                        pay[2 * stride + root] = __float_as_int(v); pay[3 * stride + root] = (int)slot;
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const unsigned long long k = keys[tid];
+    hit.t = -1.0f; hit.u = 0.0f; hit.v = 0.0f; hit.gid = 0xFFFFFFFFu; hit.slot = 0u;
+    if (ANY) return k == 0ull;
+    if (k != ~0ull) {
+        hit.gid = (uint32_t)k;
+        hit.t = __int_as_float(pay[0 * stride + tid]); hit.u = __int_as_float(pay[1 * stride + tid]);
+        hit.v = __int_as_float(pay[2 * stride + tid]); hit.slot = (uint32_t)pay[3 * stride + tid];
+    }
+    return k != ~0ull;
+}
+
 // Payload of one closest-hit query in registers (rt_types.slang:9-16).
 struct Payload {
     f3 emission;
