@@ -684,9 +684,9 @@ __global__ __launch_bounds__(kPassBlock, SR_FINAL_WAVES) void final_kernel(const
             }
             for (int s = 0; s < 3; s++) {                                              // GI_SPATIAL_SAMPLES = 3, RADIUS = 20
                 bool cand = false, want_g = false;
-                SrReservoirGI nr; zero_reservoir_gi(nr);
+                uint32_t cand_pix = 0u;   // the neighbour's reservoir is read again after the query instead of being kept in registers
                 float jacobian = 0.0f, d_new = 0.0f;
-                f3 gi_spatial_dir = splat(0.0f), nsp = splat(0.0f);
+                f3 gi_spatial_dir = splat(0.0f);
                 if (do_restir) {
                     const float gi_angle = rnd(rng) * 2.0f * 3.14159f;
                     const float gi_radius = sqrtf(rnd(rng)) * 20.0f;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(kPassBlock, SR_FINAL_WAVES) void final_kernel(const
                         ok = !(dot3(hit_normal, neighbor_normal) < 0.9f);
                         ok = ok && !(fabsf(gi_current_depth - neighbor_depth) > 0.1f * gi_current_depth);
                         if (ok) {
-                            nr = load48(reservoir_gi_cur + pi_nn);
+                            SrReservoirGI nr = load48(reservoir_gi_cur + pi_nn);
                             ok = !(nr.W <= 0.0f);                                      // :248
                             if (ok) {
                                 nr.W = fminf(nr.W, 10.0f);
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(kPassBlock, SR_FINAL_WAVES) void final_kernel(const
                                 f3 n_origin, n_dir; f2 n_uv;
                                 primary_ray(a.mats, (uint32_t)ncx, (uint32_t)ncy, W, H, n_origin, n_dir, n_uv);   // :253-258
                                 const f3 neighbor_x1 = origin + n_dir * neighbor_depth;
-                                nsp = ld3(nr.sample_pos);
+                                const f3 nsp = ld3(nr.sample_pos);
                                 const f3 w_new = nsp - hitPos;
                                 const f3 w_old = nsp - neighbor_x1;
                                 d_new = fmaxf(len3(w_new), 1e-4f);
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(kPassBlock, SR_FINAL_WAVES) void final_kernel(const
                                     jacobian = clampf(jacobian, 0.0f, 10.0f);
                                     gi_spatial_dir = w_new / d_new;
                                     ok = !(dot3(hit_normal, gi_spatial_dir) <= 0.0f);  // :273
-                                    if (ok) { cand = true; want_g = d_new > 0.002f; }
+                                    if (ok) { cand = true; cand_pix = pi_nn; want_g = d_new > 0.002f; }
                                 }
                             }
                         }
@@ -733,7 +733,10 @@ __global__ __launch_bounds__(kPassBlock, SR_FINAL_WAVES) void final_kernel(const
                 if (cand) {
                     prd.dist = want_g ? (occ ? 1.0f : -1.0f) : -1.0f;
                     if (!(prd.dist >= 0.0f)) {                                         // :287
-                        const float p_hat_neighbor = gi_target_pdf(hitPos, hit_normal, hit_albedo, metallic, nsp, ld3(nr.sample_radiance));
+                        SrReservoirGI nr = load48(reservoir_gi_cur + cand_pix);
+                        nr.W = fminf(nr.W, 10.0f);
+                        nr.M = fminf(nr.M, 10.0f);
+                        const float p_hat_neighbor = gi_target_pdf(hitPos, hit_normal, hit_albedo, metallic, ld3(nr.sample_pos), ld3(nr.sample_radiance));
                         const float gr = rnd(rng);
                         merge_reservoirs_gi(combined, nr, p_hat_neighbor, jacobian, gr);
                     }
