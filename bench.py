@@ -292,6 +292,9 @@ def main():
                 "boxes_per_ray": ck.boxes_tested / nq,
                 "tris_per_ray": ck.tris_tested / nq,
                 "other_pass_avg_ms": (ris_ms / max(ris_n, 1)) if dom == KIND_FINAL else (fin_ms / max(fin_n, 1)),
+                "note": "achieved = algorithmic bytes (32 B per box test actually executed, incl. speculative ones) / launch time; the node "
+                        "and triangle arrays are served mostly by L2 / Infinity Cache (`traffic` = physical HBM bytes per launch from the "
+                        "PMC counters), so frac is not bounded by 1: the pass is latency-bound, not HBM-bound (DESIGN.md section 5)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

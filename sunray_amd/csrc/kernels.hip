@@ -23,7 +23,10 @@ constexpr int kPassTile = kPassBlock == 256 ? 16 : 8;     // (256 threads: 16x16
 #ifndef SR_WORK_STEALING
 #define SR_WORK_STEALING 1        // 1: lanes that finish their ray early take over subtrees of the wave's busy lanes (traverse_ws)
 #endif
-constexpr int kLdsExtraRows = (SR_WORK_STEALING && SR_BVH_WIDTH != 8) ? kWsRows : 0;
+#ifndef SR_LDS_PAD_ROWS
+#define SR_LDS_PAD_ROWS 0         // experiment hook: unused LDS rows (isolates the occupancy effect of a deeper stack)
+#endif
+constexpr int kLdsExtraRows = ((SR_WORK_STEALING && SR_BVH_WIDTH != 8) ? kWsRows : 0) + SR_LDS_PAD_ROWS;
 #ifndef SR_FLAT_FINAL
 #define SR_FLAT_FINAL 1           // 1 (with SR_WORK_STEALING): predicated form of the final pass, all lanes reach every trace point
 #endif
