@@ -50,6 +50,22 @@ def balanced_bounds(row_cost, world, min_rows=8, max_share=2.5):
     return [int(v) for v in bounds]
 
 
+def refine_bounds(row_cost, bounds, periods, damping=0.7, min_rows=32, max_share=2.5):
+    """One step of the feedback balancer: `periods[r]` is the measured step time of rank r with the cut `bounds`. A rank's
+    share of a frame is about one round of waves, so its time is not proportional to the cycle sum of its rows (the strip
+    that holds the horizon rows is bound by its slowest waves): the cost model is corrected where it was wrong — the rows
+    of rank r are re-weighted by (period_r / mean period) ** damping — and the rows are cut again. Returns
+    (new row_cost, new bounds). Deterministic; the caller keeps the cut with the smallest measured maximum."""
+    import numpy as np
+    cost = np.maximum(np.asarray(row_cost, dtype=np.float64), 0.0).copy()
+    world = len(bounds) - 1
+    p = np.maximum(np.asarray(periods, dtype=np.float64), 1e-9)
+    mean = float(p.mean())
+    for r in range(world):
+        cost[bounds[r]:bounds[r + 1]] *= (p[r] / mean) ** damping
+    return cost, balanced_bounds(cost, world, min_rows=min_rows, max_share=max_share)
+
+
 def row_cost_from_depth(depth_u16, width, height, sky_weight=1.0, surface_weight=4.0):
     """Per-row cost estimate from a G-buffer depth image (R16F bits): a sky pixel (depth +inf, ray_gen_ris.slang:168)
     costs one primary ray per pass, a surface pixel the whole ReSTIR sequence (~6 rays, mostly incoherent)."""

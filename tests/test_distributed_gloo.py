@@ -81,6 +81,17 @@ def test_strip_helpers():
     assert max(shares) / np.mean(shares) < 1.02 < (4.0 * 135) / (cost.sum() / 8)      # equal rows would be 26 % off
     assert max(sd.balanced_bounds(cost, 8, max_share=1.5)[i + 1] - sd.balanced_bounds(cost, 8, max_share=1.5)[i] for i in range(8)) <= 203
     assert sd.balanced_bounds(np.zeros(10), 4) == [0, 3, 6, 8, 10] and sd.balanced_bounds(np.ones(5), 8)[-1] == 5
+    # feedback balancer: a synthetic machine whose ranks cost `sum(rows) + a floor for the strip holding rows 300..400`
+    def machine(b):
+        return [cost[b[i]:b[i + 1]].sum() / 400.0 + (0.4 if b[i] < 400 and b[i + 1] > 300 else 0.0) for i in range(8)]
+    rc, bb, best = cost.copy(), sd.balanced_bounds(cost, 8), None
+    first = max(machine(bb))
+    for _ in range(4):
+        p = machine(bb)
+        best = min(best or 1e9, max(p))
+        rc, bb = sd.refine_bounds(rc, bb, p)
+        assert bb[0] == 0 and bb[-1] == 1080 and all(bb[i + 1] - bb[i] >= 32 for i in range(8))
+    assert best < first * 0.95                      # the slow strip was shrunk
     depth = np.full((4, 6), 0x7C00, dtype=np.uint16); depth[2:] = 0x4000
     assert list(sd.row_cost_from_depth(depth, 6, 4)) == [6.0, 6.0, 24.0, 24.0]
 
