@@ -85,7 +85,7 @@ struct SrScene {
     // acceleration-structure maintenance (update in place): per-level node lists, exact node boxes, flatten inputs
     DeviceBuffer d_level_nodes, d_node_box, d_mesh_infos, d_flat_instances, d_scratch;
     // cost-ordered tile schedules of the two passes (kernels.hip thread_pixel), one per launch geometry
-    struct TileSchedule { int which = -1; uint32_t width = 0, y0 = 0, y1 = 0; DeviceBuffer cost, order; bool have_order = false; uint64_t last_use = 0; };
+    struct TileSchedule { int which = -1; uint32_t width = 0, y0 = 0, y1 = 0; DeviceBuffer cost, order; bool have_order = false; uint64_t last_use = 0; uint32_t uses = 0; };
     std::vector<TileSchedule> schedules;
     uint64_t schedule_clock = 0;
     int tile_scheduling = 1;                // SR_TILE_SCHEDULING=0 in the environment disables it (A/B)
@@ -805,7 +805,7 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
             const size_t bytes = (size_t)srk_pass_tile_count(p->width, y1 - y0) * 4;
             if ((rc = sched->cost.reserve(bytes)) != SR_OK || (rc = sched->order.reserve(bytes)) != SR_OK) return rc;
             HIP_TRY(hipMemsetAsync(sched->cost.p, 0, bytes, st));
-            sched->which = which; sched->width = p->width; sched->y0 = y0; sched->y1 = y1; sched->have_order = false;
+            sched->which = which; sched->width = p->width; sched->y0 = y0; sched->y1 = y1; sched->have_order = false; sched->uses = 0;
         }
         sched->last_use = ++s->schedule_clock;
         a.tile_cost = (uint32_t*)sched->cost.p;
@@ -817,7 +817,9 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
         e = srk_launch_pass(a, which, s->instrumented, s->dev.shade_tex != nullptr, s->stack_entries, st);
     }
     if (e != 0) return fail(SR_ERR_HIP, std::string(name) + " launch: " + hipGetErrorString((hipError_t)e));
-    if (sched) {
+    // The sweep direction changes rarely (it follows where the expensive rows are): re-derive it after the first launches
+    // of a geometry and then every 16th, not after every launch (a 9 us kernel plus its launch gap per pass).
+    if (sched && (sched->uses++ < 4 || (sched->uses & 15u) == 0u)) {
         e = srk_launch_tile_order((const uint32_t*)sched->cost.p, (uint32_t*)sched->order.p, p->width, y1 - y0, st);
         if (e != 0) return fail(SR_ERR_HIP, std::string(name) + " tile schedule: " + hipGetErrorString((hipError_t)e));
         sched->have_order = true;
