@@ -42,6 +42,8 @@ def rays_for(rng, desc, osc, n, scale):
     o[3 * k:4 * k] = (tri[:, 0] * 0.3 + tri[:, 1] * 0.3 + tri[:, 2] * 0.4).astype(np.float32)
     r = np.zeros(n, dtype=abi.RAY)
     r["origin"] = o; r["dir"] = d.astype(np.float32); r["tmin"] = 0.001 * min(scale, 1.0); r["tmax"] = 1e4 * scale
+    r["tmin"][::7] = -2.0 * scale * rng.random(len(r["tmin"][::7])).astype(np.float32)       # hits behind the origin are legal queries
+    r["tmax"][3::5] = (scale * 3.0 * rng.random(len(r["tmax"][3::5]))).astype(np.float32)    # short segments
     return r
 
 bad = 0

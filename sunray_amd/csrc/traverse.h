@@ -157,7 +157,8 @@ SRD bool child_hit(const NodePlanes& p, float t_lo, float t_hi, float& tnear) {
     const float t0 = fmaxf(fmaxf(fmaf(plane_q<C>(p.nx), p.ax, p.bx), fmaf(plane_q<C>(p.ny), p.ay, p.by)),
                            fmaxf(fmaf(plane_q<C>(p.nz), p.az, p.bz), t_lo));
     float far = fminf(fminf(fmaf(plane_q<C>(p.fx), p.ax, p.bx), fmaf(plane_q<C>(p.fy), p.ay, p.by)), fmaf(plane_q<C>(p.fz), p.az, p.bz));
-    far = far * 1.0000005f;   // a negative far bound moves further away from every valid t > 0: harmless; +-inf stay
+    far = fmaf(fabsf(far), 5e-7f, far);   // inflate towards +inf whatever the sign (queries with tmin < 0 accept hits at negative t);
+                                          // one v_fma with an |x| modifier. -inf gives NaN, which v_min drops: not culled, conservative
     tnear = t0;
     return t0 <= fminf(far, t_hi);
 }

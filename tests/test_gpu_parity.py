@@ -148,6 +148,39 @@ def test_trace_medium_scenes_equal_oracle_bvh(rt, oracle):
         assert np.array_equal(osc.trace_any(rays), gsc.trace_any(rd, len(rays)).cpu().numpy().view(np.uint32))
 
 
+def test_trace_lone_long_rays_and_coincident_twins(rt, oracle):
+    """The traversal hands subtrees of busy lanes to idle lanes of the same wave and merges the partial results by
+    (t, triangle id): waves with ONE long ray (grazing the whole terrain) among 63 trivial ones force that path, a second
+    instance of the same mesh at the same place gives every hit an equal-t twin with a higher id in another subtree, and
+    negative tmin / short tmax exercise the ordered-key encoding of t."""
+    desc = scenes.heightfield(n=160)
+    key, xf = desc.instances[0]
+    desc.instances[0] = (key, list(xf) + [xf[0].copy()])                   # coincident twin instance
+    osc = oracle.OracleScene().load(desc)
+    gsc = rt.Scene(0).load(desc)
+    n_tris_one = len(desc.meshes[0].indices) // 3
+    rng = np.random.default_rng(77)
+    n = 64 * 300
+    o = np.zeros((n, 3), np.float32); d = np.zeros((n, 3), np.float32)
+    o[:] = (rng.random((n, 3)) * [30, 0, 30] + [-15, 12, -15]); d[:] = (0, 1, 0)        # trivial: above the terrain, pointing up
+    long_ = np.arange(0, n, 64) + rng.integers(0, 64, n // 64)
+    ang = rng.random(len(long_)) * 2 * np.pi
+    o[long_] = np.stack([-16 * np.cos(ang), 2.0 + 6 * rng.random(len(long_)), -16 * np.sin(ang)], 1)
+    d[long_] = np.stack([np.cos(ang), -0.02 * rng.random(len(long_)), np.sin(ang)], 1)   # grazing, across the whole field
+    rays = make_rays(o, d / np.linalg.norm(d, axis=1, keepdims=True))
+    mixed = random_rays(64 * 200, 78, box=((-15, 0, -15), (15, 9, 15)))
+    mixed["tmin"][::3] = -5.0                                                            # hits behind the origin are legal
+    mixed["tmax"][1::4] = rng.random(len(mixed["tmax"][1::4])).astype(np.float32) * 3
+    rays = np.concatenate([rays, mixed])
+    rd = rt.rays_to_device(rays)
+    hits = rt.hits_from_device(gsc.trace_closest(rd, len(rays)))
+    assert_bits_equal(osc.trace_closest(rays), hits, "closest hits, lone long rays")
+    assert np.array_equal(osc.trace_any(rays), gsc.trace_any(rd, len(rays)).cpu().numpy().view(np.uint32))
+    hit = hits["tri"] != 0xFFFFFFFF
+    assert hit[long_].mean() > 0.3 and (hits["tri"][hit] < n_tris_one).all()            # always the first copy, never the twin
+    assert (hits["t"][hit] < 0).any()
+
+
 # ---- K4 / K6: closest_hit / miss ------------------------------------------------------------------
 def test_shade_closest_hit_payloads(rt, oracle):
     desc = scenes.cornell_glass_mirror()  # includes a rotated + scaled instance: non-trivial WorldToObject
