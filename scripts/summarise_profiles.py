@@ -12,7 +12,7 @@ for f in ('fetch', 'write', 'sq1', 'sq2', 'ta1', 'ta2'):
 lines = ["# rocprofv3 --pmc, mean per launch over the launches of `python bench.py --no-cpu-baseline --steps 5 --warmup 2` (1x MI355X).",
          "# One counter group per run (FETCH_SIZE | WRITE_SIZE | SQ group 1 | SQ group 2 | TA_TA_BUSY+GRBM_GUI_ACTIVE | TA stalls); SQ_* cycle counters are in quad-cycles,",
          "# *_sum counters are summed over the 256 CUs, GRBM_GUI_ACTIVE over the 8 XCDs. Build: quantised BVH4 (leaves <= 2 triangles), folded plane test,",
-         "# nearest-first branch-free pushes, 64-thread workgroups, cost-aware tile sweep."]
+         "# nearest-first branch-free pushes, 64-thread workgroups, cost-aware tile sweep, speculative traversal, work stealing inside the wave, predicated final pass."]
 m = {}
 for (k, c), v in sorted(rows.items()):
     m[(k, c)] = sum(v) / len(v)
