@@ -551,7 +551,7 @@ int sr_default_noise_texture(uint32_t w, uint32_t h, uint32_t seed, uint8_t* out
 int sr_scene_read_tile_row_costs(SrScene* scene, int which, uint32_t width, uint32_t y0, uint32_t rows, double* out,
                                  uint32_t cap, uint32_t* n_tile_rows);
 
-/* The same measurement per tile (8x8 pixels), in the band-major order the kernels use: tuning diagnostics. */
+/* The same measurement per tile (8x8 pixels), row-major (tile row * tiles per row + tile column): tuning diagnostics. */
 int sr_scene_read_tile_costs(SrScene* scene, int which, uint32_t width, uint32_t y0, uint32_t rows, uint32_t* out,
                              uint32_t cap, uint32_t* n_tiles);
 

@@ -26,12 +26,15 @@ for which, name, ms in ((0, "ris", a), (1, "final", b)):
 out = np.zeros(40000, dtype=np.uint32); n = C.c_uint32()
 check(lib().sr_scene_read_tile_costs(sc._h, 1, W, 0, H, out.ctypes.data_as(C.c_void_p), len(out), C.byref(n)))
 tiles_x, tiles_y = W // 8, H // 8
-grid = np.zeros((tiles_y, tiles_x))
-for xcd in range(8):
-    bx0, bx1 = (tiles_x * xcd) >> 3, (tiles_x * (xcd + 1)) >> 3
-    bw = bx1 - bx0
-    seg = out[bx0 * tiles_y: bx0 * tiles_y + bw * tiles_y].astype(np.float64) / 2100.0
-    grid[:, bx0:bx1] = seg.reshape(tiles_y, bw)
+grid = out[:tiles_x * tiles_y].astype(np.float64).reshape(tiles_y, tiles_x) / 2100.0
 for r0 in range(0, tiles_y, 9):
     g = grid[r0:r0 + 9]
     print("pixel rows %4d-%4d: mean %.0f us  max %.0f us" % (r0 * 8, min((r0 + 9) * 8, H) - 1, g.mean(), g.max()))
+# per tile column: summed wave time of both passes; equal-width XCD bands vs what the library's cost-balanced bands even out
+col = np.zeros(tiles_x)
+for which in (0, 1):
+    out = np.zeros(40000, dtype=np.uint32); n = C.c_uint32()
+    check(lib().sr_scene_read_tile_costs(sc._h, which, W, 0, H, out.ctypes.data_as(C.c_void_p), len(out), C.byref(n)))
+    col += out[:tiles_x * tiles_y].astype(np.float64).reshape(tiles_y, tiles_x).sum(axis=0) / 2100.0
+eq = np.array([col[(tiles_x * i) >> 3:(tiles_x * (i + 1)) >> 3].sum() for i in range(8)])
+print("equal-width bands, wave time per band (ms of one wave slot): %s | max / mean = %.3f" % (" ".join("%.0f" % (t / 1e3) for t in eq), eq.max() / eq.mean()))

@@ -803,7 +803,7 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
             for (auto& ts : s->schedules) if (ts.which < 0 || ts.last_use < sched->last_use) sched = &ts;
             if (sched->which >= 0) HIP_TRY(hipStreamSynchronize(st));          // recycling an entry a launch may still read
             const size_t bytes = (size_t)srk_pass_tile_count(p->width, y1 - y0) * 4;
-            if ((rc = sched->cost.reserve(bytes)) != SR_OK || (rc = sched->order.reserve(bytes)) != SR_OK) return rc;
+            if ((rc = sched->cost.reserve(bytes)) != SR_OK || (rc = sched->order.reserve((size_t)srk_pass_order_cap(p->width, y1 - y0) * 8 * 4)) != SR_OK) return rc;
             HIP_TRY(hipMemsetAsync(sched->cost.p, 0, bytes, st));
             sched->which = which; sched->width = p->width; sched->y0 = y0; sched->y1 = y1; sched->have_order = false; sched->uses = 0;
         }
@@ -843,15 +843,15 @@ int sr_scene_read_tile_row_costs(SrScene* s, int which, uint32_t width, uint32_t
     std::vector<uint32_t> cost(n_tiles);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(cost.data(), sched->cost.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost));
-    for (uint32_t r = 0; r < tiles_y; r++) out[r] = 0.0;
-    for (uint32_t xcd = 0; xcd < 8; xcd++) {                    // band-major layout of thread_pixel (kernels.hip)
-        const uint32_t bx0 = (tiles_x * xcd) >> 3, bx1 = (tiles_x * (xcd + 1u)) >> 3, bw = bx1 - bx0;
-        for (uint32_t t = 0; t < bw * tiles_y; t++) out[t / bw] += (double)cost[(size_t)bx0 * tiles_y + t];
+    for (uint32_t r = 0; r < tiles_y; r++) {                    // cost slots are absolute tile indices (thread_pixel, kernels.hip)
+        double sum = 0.0;
+        for (uint32_t x = 0; x < tiles_x; x++) sum += (double)cost[(size_t)r * tiles_x + x];
+        out[r] = sum;
     }
     return SR_OK;
 }
 
-// The same data per tile (band-major order of thread_pixel): tuning diagnostics.
+// The same data per tile, row-major (ty * tiles_x + tx): tuning diagnostics.
 int sr_scene_read_tile_costs(SrScene* s, int which, uint32_t width, uint32_t y0, uint32_t rows, uint32_t* out, uint32_t cap, uint32_t* n_tiles_out) {
     if (!s || !out || !n_tiles_out) return fail(SR_ERR_INVALID_ARG, "sr_scene_read_tile_costs: null argument");
     SrScene::TileSchedule* sched = nullptr;

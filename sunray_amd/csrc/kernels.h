@@ -24,7 +24,7 @@ struct PassArgs {
     uint32_t width, height;
     uint32_t y0, y1;              // rows [y0, y1) of the image are traced by this launch
     uint32_t tiles_x, tiles_y;    // pixel tiles covering width x (y1 - y0); filled in by srk_launch_pass
-    uint32_t tiles_per_xcd;       // ceil(tiles_x / 8) * tiles_y: blocks per XCD (column bands)
+    uint32_t order_cap;           // blocks per XCD = entries per XCD in tile_order (srk_pass_order_cap)
     // cost-ordered tile schedule (kernels.hip): this launch's per-tile cost is written to tile_cost, the order derived
     // from the PREVIOUS launch's costs is read from tile_order (null on the first launch of a geometry)
     uint32_t* tile_cost;
@@ -40,6 +40,8 @@ int srk_launch_shade(const srd::DevScene& sc, const SrHit* hits, uint32_t n, SrR
 int srk_launch_pass(const srd::PassArgs& args, int which, int stats, int textured, int stack_entries, hipStream_t stream);
 // Tile schedule of the next launch from this launch's costs: per XCD band, tiles in descending cost (64 buckets).
 uint32_t srk_pass_tile_count(uint32_t width, uint32_t rows);
+uint32_t srk_pass_order_cap(uint32_t width, uint32_t rows);
+uint32_t srk_pass_tiles_x(uint32_t width);
 int srk_launch_tile_order(const uint32_t* tile_cost, uint32_t* tile_order, uint32_t width, uint32_t rows, hipStream_t stream);
 
 int srk_launch_post_temporal(const SrPostParams& p, hipStream_t stream);

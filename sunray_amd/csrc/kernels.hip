@@ -10,6 +10,7 @@
 // slowest wave finished). Workgroups are dealt to screen tiles XCD-aware: blocks b and b+8 share an XCD (round-robin
 // dispatch), XCD x owns column band x of the image, so its private 4 MiB L2 holds the part of the BVH under that band;
 // inside a band the rows are swept from the expensive end to the cheap end (thread_pixel, tile_order_kernel).
+#include <algorithm>
 #include "kernels.h"
 
 namespace srd {
@@ -218,25 +219,32 @@ SRD LightTri fetch_light(const DevScene& sc, uint32_t idx) {
 
 // Map this thread to its pixel. Returns false for threads outside the image / tile.
 // XCD-aware and load-balanced: the image is cut into 8 COLUMN bands, one per XCD (blocks b and b+8
-// share an XCD under round-robin dispatch), walked row-major inside the band. Cost varies mostly with
+// share an XCD under round-robin dispatch), walked row by row inside the band. Cost varies mostly with
 // image row (distance to the terrain), so column bands give every XCD the same mix of rows, while the
 // tiles an XCD works on at any moment stay neighbours and share its 4 MiB L2.
-// The order of a band's tiles comes from tile_order (tile_order_kernel, derived from the previous launch's measured
-// costs): the launch then drains with cheap tiles instead of ending on a front of expensive ones (a frame's cost is
-// spatially correlated: sky rows finish in a fraction of the time of terrain rows). Scheduling only — results do not
-// depend on it. `tile` = index of the tile inside its band, also the index of its cost slot.
+// Both the band boundaries and the order of a band's tiles come from tile_order (tile_order_kernel, derived from the
+// measured costs of an earlier launch): bands of equal summed cost instead of equal width (the image centre is more
+// expensive than its edges: equal widths left the two outer XCDs 30 % short of work), and each band swept from its
+// expensive end to its cheap end, so the launch drains with cheap tiles instead of ending on a front of expensive
+// ones (a frame's cost is spatially correlated: sky rows finish in a fraction of the time of terrain rows).
+// Scheduling only — results do not depend on it. tile_order holds, per XCD, `order_cap` absolute tile indices
+// (ty * tiles_x + tx; 0xFFFFFFFF past the end of the XCD's list); cost slots are absolute tile indices.
 SRD bool thread_pixel(const PassArgs& a, uint32_t& px, uint32_t& py, uint32_t& cost_slot) {
     const uint32_t b = blockIdx.x;
     const uint32_t xcd = b & 7u, k = b >> 3;
-    const uint32_t bx0 = (a.tiles_x * xcd) >> 3, bx1 = (a.tiles_x * (xcd + 1u)) >> 3;  // this XCD's tile columns
-    const uint32_t bw = bx1 - bx0;
     cost_slot = 0xFFFFFFFFu;
-    if (bw == 0u || k >= bw * a.tiles_y) return false;
-    const uint32_t band_base = bx0 * a.tiles_y;
-    uint32_t tile = k;
-    if (a.tile_order) { tile = a.tile_order[band_base + k]; if (tile >= bw * a.tiles_y) tile = k; }
-    cost_slot = band_base + tile;
-    const uint32_t tx = bx0 + tile % bw, ty = tile / bw;
+    uint32_t tile;
+    if (a.tile_order) {
+        tile = a.tile_order[xcd * a.order_cap + k];                                         // k < order_cap by the grid size
+    } else {                                                                                // no measured costs yet: equal widths, top to bottom
+        const uint32_t bx0 = (a.tiles_x * xcd) >> 3, bx1 = (a.tiles_x * (xcd + 1u)) >> 3;
+        const uint32_t bw = bx1 - bx0;
+        if (bw == 0u || k >= bw * a.tiles_y) return false;
+        tile = (k / bw) * a.tiles_x + bx0 + k % bw;
+    }
+    if (tile >= a.tiles_x * a.tiles_y) return false;
+    cost_slot = tile;
+    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
     px = tx * (uint32_t)kPassTile + (w & 1u) * 8u + (l & 7u);
     py = a.y0 + ty * (uint32_t)kPassTile + (w >> 1) * 8u + (l >> 3);
@@ -249,29 +257,76 @@ SRD void record_tile_cost(const PassArgs& a, uint32_t cost_slot, unsigned long l
     }
 }
 
-// One workgroup per band: the band is swept row by row from its expensive end to its cheap end (the direction is
-// the only choice made from the measured costs: first quarter of rows vs last quarter), tiles of a row in x order.
-// A monotone sweep keeps concurrently running tiles adjacent (shared BVH nodes in the XCD's L2) and still ends the
-// launch on cheap tiles. Measured against the fixed top-to-bottom order on the bench frame: sweep from the expensive
-// end +8 %, rows ranked by cost +6 %, tiles ranked by cost +5 %.
-__global__ void tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t tiles_x, uint32_t tiles_y) {
+// Widest band the schedule may form, in tile columns (the launch is sized for it): 1.5x the equal share.
+SRD uint32_t band_cap_cols_dev(uint32_t tiles_x) { return min(tiles_x, (tiles_x * 3u) / 16u + 2u); }
+
+// One workgroup per XCD band. Every workgroup sums the measured cost per tile column, thread 0 cuts the columns into 8
+// bands of (nearly) equal cost (each at most band_cap_cols wide), then the workgroup writes its band's tile list: swept
+// row by row from the band's expensive end to its cheap end (first quarter of rows vs last quarter), tiles of a row in
+// x order. A monotone sweep keeps concurrently running tiles adjacent (shared BVH nodes in the XCD's L2) and still
+// ends the launch on cheap tiles. Measured against the fixed top-to-bottom order on the bench frame: sweep from the
+// expensive end +8 %, rows ranked by cost +6 %, tiles ranked by cost +5 %; cost-balanced bands: see DESIGN.md.
+constexpr uint32_t kMaxScheduleCols = 1024;   // 8192-pixel-wide images; wider ones keep equal-width bands
+__global__ void tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t tiles_x, uint32_t tiles_y, uint32_t order_cap) {
+    __shared__ unsigned long long s_col[kMaxScheduleCols];
+    __shared__ uint32_t s_b[9];
     __shared__ unsigned long long s_sum[2];
-    const uint32_t xcd = blockIdx.x;
-    const uint32_t bx0 = (tiles_x * xcd) >> 3, bx1 = (tiles_x * (xcd + 1u)) >> 3;
-    const uint32_t bw = bx1 - bx0, base = bx0 * tiles_y, n = bw * tiles_y;
-    if (bw == 0u) return;
+    const uint32_t band = blockIdx.x;
+    const uint32_t cap_cols = band_cap_cols_dev(tiles_x);
+    const bool balance = tiles_x <= kMaxScheduleCols && tiles_x >= 16u;
+    if (balance) {
+        for (uint32_t x = threadIdx.x; x < tiles_x; x += blockDim.x) {
+            unsigned long long c = 0;
+            for (uint32_t y = 0; y < tiles_y; y++) c += cost[(size_t)y * tiles_x + x];
+            s_col[x] = c + 1ull;                                   // + 1: columns of an unmeasured image still spread evenly
+        }
+    }
     if (threadIdx.x < 2) s_sum[threadIdx.x] = 0;
     __syncthreads();
+    if (threadIdx.x == 0) {
+        s_b[0] = 0u; s_b[8] = tiles_x;
+        if (balance) {
+            unsigned long long total = 0;
+            for (uint32_t x = 0; x < tiles_x; x++) total += s_col[x];
+            unsigned long long run = 0;
+            uint32_t x = 0;
+            for (uint32_t i = 1; i < 8u; i++) {
+                const unsigned long long target = total / 8ull * i;
+                while (x < tiles_x && run + s_col[x] / 2ull < target) run += s_col[x++];    // the column goes to the side its centre lies on
+                uint32_t cut = x;
+                cut = max(cut, s_b[i - 1] + 1u);                                            // at least one column per band
+                cut = min(cut, s_b[i - 1] + cap_cols);                                      // at most cap_cols
+                cut = max(cut, tiles_x > (8u - i) * cap_cols ? tiles_x - (8u - i) * cap_cols : 0u);   // the bands that are left can cover the rest
+                cut = min(cut, tiles_x - (8u - i));                                         // ... and each gets a column
+                while (x < cut) run += s_col[x++];
+                s_b[i] = cut;
+            }
+        } else {
+            for (uint32_t i = 1; i < 8u; i++) s_b[i] = (tiles_x * i) >> 3;
+        }
+    }
+    __syncthreads();
+    const uint32_t bx0 = s_b[band], bx1 = s_b[band + 1];
+    const uint32_t bw = bx1 - bx0, n = bw * tiles_y;
+    uint32_t* const mine = order + (size_t)band * order_cap;
     const uint32_t q = max(tiles_y / 4u, 1u) * bw;      // tiles in a quarter of the rows
     unsigned long long head = 0, tail = 0;
-    for (uint32_t i = threadIdx.x; i < q; i += blockDim.x) { head += cost[base + i]; tail += cost[base + n - 1u - i]; }
+    for (uint32_t i = threadIdx.x; i < q; i += blockDim.x) {
+        const uint32_t r = i / bw, x = bx0 + i % bw;
+        head += cost[(size_t)r * tiles_x + x];
+        tail += cost[(size_t)(tiles_y - 1u - r) * tiles_x + x];
+    }
     atomicAdd(&s_sum[0], head);
     atomicAdd(&s_sum[1], tail);
     __syncthreads();
     const bool bottom_up = s_sum[1] > s_sum[0];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t r = i / bw, x = i % bw;
-        order[base + i] = (bottom_up ? tiles_y - 1u - r : r) * bw + x;
+    for (uint32_t i = threadIdx.x; i < order_cap; i += blockDim.x) {
+        uint32_t t = 0xFFFFFFFFu;
+        if (i < n) {
+            const uint32_t r = i / bw, x = i % bw;
+            t = (bottom_up ? tiles_y - 1u - r : r) * tiles_x + bx0 + x;
+        }
+        mine[i] = t;
     }
 }
 
@@ -1176,10 +1231,10 @@ int srk_launch_pass(const PassArgs& args_in, int which, int stats, int textured,
     PassArgs args = args_in;
     args.tiles_x = (args.width + kPassTile - 1) / kPassTile;
     args.tiles_y = (args.y1 - args.y0 + kPassTile - 1) / kPassTile;
-    args.tiles_per_xcd = ((args.tiles_x + 7) / 8) * args.tiles_y;   // widest column band x rows (thread_pixel)
+    args.order_cap = srk_pass_order_cap(args.width, args.y1 - args.y0);   // list length per XCD = blocks per XCD
     const uint32_t n_tiles = args.tiles_x * args.tiles_y;
     if (n_tiles == 0) return 0;
-    dim3 grid(args.tiles_per_xcd * 8), block(kPassBlock);
+    dim3 grid(args.order_cap * 8), block(kPassBlock);
     const size_t lds = (size_t)(stack_entries + kLdsExtraRows) * kPassBlock * sizeof(int);
     const int v = (stats ? 1 : 0) | (textured ? 2 : 0);
     if (which == 0) {
@@ -1201,10 +1256,18 @@ int srk_launch_pass(const PassArgs& args_in, int which, int stats, int textured,
 }
 
 uint32_t srk_pass_tile_count(uint32_t width, uint32_t rows) { return ((width + kPassTile - 1) / kPassTile) * ((rows + kPassTile - 1) / kPassTile); }
+uint32_t srk_pass_tiles_x(uint32_t width) { return (width + kPassTile - 1) / kPassTile; }
+
+// Entries per XCD of the tile schedule (= blocks per XCD of a pass launch): the widest band the schedule may form.
+uint32_t srk_pass_order_cap(uint32_t width, uint32_t rows) {
+    const uint32_t tiles_x = (width + kPassTile - 1) / kPassTile, tiles_y = (rows + kPassTile - 1) / kPassTile;
+    const uint32_t cap_cols = std::max(std::min(tiles_x, (tiles_x * 3u) / 16u + 2u), (tiles_x + 7u) / 8u);
+    return cap_cols * tiles_y;
+}
 
 int srk_launch_tile_order(const uint32_t* tile_cost, uint32_t* tile_order, uint32_t width, uint32_t rows, hipStream_t stream) {
     const uint32_t tiles_x = (width + kPassTile - 1) / kPassTile, tiles_y = (rows + kPassTile - 1) / kPassTile;
     if (tiles_x * tiles_y == 0) return 0;
-    tile_order_kernel<<<dim3(8), dim3(256), 0, stream>>>(tile_cost, tile_order, tiles_x, tiles_y);
+    tile_order_kernel<<<dim3(8), dim3(256), 0, stream>>>(tile_cost, tile_order, tiles_x, tiles_y, srk_pass_order_cap(width, rows));
     return (int)hipGetLastError();
 }
