@@ -723,7 +723,7 @@ static int trace_queue(SrScene* s, const SrRay* rays, uint32_t n, SrHit* hits, u
     if (rc != SR_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     uint32_t* queue_head = (uint32_t*)((char*)s->d_misc.p + 32);
-    const int lds_per_block = s->stack_entries * 256 * 4;
+    const int lds_per_block = srk_lds_rows(s->stack_entries) * 256 * 4;
     int per_cu = std::max(1, std::min(8, 160 * 1024 / lds_per_block));  // persistent grid = LDS-limited residency
     if (const char* e = getenv("SR_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));   // tuning switch
     const int n_blocks = s->n_cus * per_cu;

@@ -39,6 +39,7 @@ int srk_launch_trace(const srd::DevScene& sc, const SrRay* rays, uint32_t n, SrH
 int srk_launch_shade(const srd::DevScene& sc, const SrHit* hits, uint32_t n, SrRayPayload* out, hipStream_t stream);
 int srk_launch_pass(const srd::PassArgs& args, int which, int stats, int textured, int stack_entries, hipStream_t stream);
 // Tile schedule of the next launch from this launch's costs: per XCD band, tiles in descending cost (64 buckets).
+int srk_lds_rows(int stack_entries);
 uint32_t srk_pass_tile_count(uint32_t width, uint32_t rows);
 uint32_t srk_pass_order_cap(uint32_t width, uint32_t rows);
 uint32_t srk_pass_tiles_x(uint32_t width);
