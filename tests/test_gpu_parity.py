@@ -306,6 +306,14 @@ def test_passes_equal_oracle(rt, oracle, blue_noise, scene_fn, W, H, frames):
     run_both(rt, oracle, scene_fn(), W, H, frames, blue_noise)
 
 
+@pytest.mark.parametrize("W,H", [(5, 3), (8, 8), (130, 17), (1000, 9), (24, 300), (129, 129)])
+def test_passes_odd_extents_through_tile_schedule_updates(rt, oracle, blue_noise, W, H):
+    """Fewer tile columns than XCD bands, one tile row, tall and narrow: the launch geometry and the cost-derived tile
+    schedule (bands of equal cost, sweep direction; re-derived after each of the first launches) must cover every pixel
+    exactly once — five consecutive frames, every buffer bit-exact."""
+    run_both(rt, oracle, scenes.cornell_box(), W, H, 5, blue_noise)
+
+
 def test_passes_without_restir_and_bounce_knobs(rt, oracle, blue_noise):
     cfg = abi.SrTraceConfig.reference()
     cfg.enable_restir, cfg.max_bounces, cfg.shadow_bounces = 0, 2, 2   # BASELINE.json config 3 settings
