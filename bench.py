@@ -251,7 +251,7 @@ def main():
     fence()
 
     scene.reset_counters()
-    scene.enable_timing(True)
+    scene.enable_timing(os.environ.get("SUNRAY_BENCH_TIMING", "1") == "1")
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -286,7 +286,7 @@ def main():
         # with N > 1 the RIS pass is 1 strip launch + up to 2 halo launches per step: price it per step
         avg_ms = dom_ms / max(dom_n, 1) if (dom == KIND_FINAL or world == 1) else dom_ms / args.steps
         bytes_per_launch = algorithmic_bytes(per_kind[dom], W * h, dom)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0   # SUNRAY_BENCH_TIMING=0 (tuning): no per-launch events
         ck = per_kind[dom]
         nq = max(ck.closest_queries + ck.any_queries, 1)
         out = {
