@@ -253,6 +253,10 @@ SRD bool thread_pixel(const PassArgs& a, uint32_t& px, uint32_t& py, uint32_t& c
 SRD void record_tile_cost(const PassArgs& a, uint32_t cost_slot, unsigned long long t_start) {
     if (a.tile_cost && cost_slot != 0xFFFFFFFFu && threadIdx.x == 0) {
         const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
+#if SR_DIAG_TIMELINE   // diagnostics (scripts/gpu_wave_timeline.py): in frame SR_DIAG_TIMELINE the slot holds the wave's END time on the
+                       // device-wide 100 MHz counter (20 bits) << 12 | its duration in units of 256 shader cycles
+        if (a.frame_count == SR_DIAG_TIMELINE) { a.tile_cost[cost_slot] = (uint32_t)((__builtin_amdgcn_s_memrealtime() & 0xFFFFFull) << 12) | (uint32_t)min(dt >> 8, 0xFFFull); return; }
+#endif
         a.tile_cost[cost_slot] = (uint32_t)(dt > 0xFFFFFFFFull ? 0xFFFFFFFFull : dt);
     }
 }
