@@ -21,7 +21,9 @@ for which, name in ((0, "ris"), (1, "final")):
     v = out[:n.value].astype(np.int64)
     end = ((v >> 12) & 0xFFFFF) * 0.01                  # us on the device-wide 100 MHz counter
     dur_cyc = (v & 0xFFF) * 256.0
-    end = (end - end.min()) % (0x100000 * 0.01)
+    wrap = 0x100000 * 0.01                                # the 20 bits kept wrap every 10.5 ms: unwrap around the median
+    end = (end - np.median(end) + wrap / 2) % wrap
+    end -= end.min()
     # shader clock from the data: at most 4096 waves are resident at any time
     def resident(ghz, n=200):
         st = end - dur_cyc / (ghz * 1e3)
