@@ -2,8 +2,10 @@
 """bench.py — headline benchmark of the MI355X ray-tracing hot path.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...            (no launcher: starts torch.distributed.run with N ranks as a child and relays the line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    SUNRAY_BENCH_ONE_DEVICE=1 python bench.py --gpus 4   (rehearsal on a 1-GPU box: every rank on cuda:0, gather over gloo)
 
 Workload (BASELINE.json `metric`: "Mray/s + ms/frame at 1920x1080 1spp, 1M-tri scene"): one step =
 one frame = the two ray-tracing passes of the reference (raytracing_ris + raytracing_final,
@@ -15,6 +17,9 @@ queries actually issued). With N GPUs the frame's rows are split into N strips (
 frame; sunray_amd/distributed.py) and the radiance strips are all-gathered over RCCL every step.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+`roofline` holds three physical bounds per pass (HBM traffic, L2-resident gather rate, VALU issue), each a fraction <= 1;
+the HBM traffic and the VALU / cache counters are measured live at N = 1: before touching the GPU the process runs four
+short `rocprofv3 --pmc` passes of this same workload as child processes (about a minute; --no-pmc skips them).
 """
 import argparse
 import json
@@ -26,14 +31,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
+L2_GATHER_PEAK_GBS = 17800.0  # MI355X_MICROARCH.md "Indexed rows: gather into LDS": rows served from the XCDs' L2, 16.8-18.8 TB/s chip-wide
+N_SIMD = 1024                 # 256 CUs x 4 SIMD-32; one wave64 VALU instruction occupies a SIMD for 2 cycles
 KIND_RIS, KIND_FINAL = 0, 1
+KERNEL_OF = {KIND_RIS: "ris_kernel", KIND_FINAL: "final_kernel"}
+
+# Counter groups of the live PMC passes (one rocprofv3 --pmc run each: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2,
+# MI355X_MICROARCH.md "rocprofv3 PMC slots"; GRBM has its own slots).
+PMC_GROUPS = [
+    ["FETCH_SIZE"],
+    ["WRITE_SIZE"],
+    ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"],
+    ["TCC_HIT_sum", "TCC_MISS_sum", "TA_TA_BUSY_sum"],
+]
 
 
-def algorithmic_bytes(c, n_pixels, which):
-    """B_ray = 32*N_boxes + 48*N_tris + 32 (ray) + 16 (hit) per query, +460 B per
-    closest-hit surface fetch (128 MeshInfo + 12 indices + 288 vertices + 32 payload), plus the
-    per-pixel frame-buffer traffic of the pass (reference formats)."""
+def survey_bytes(c, n_pixels, which):
+    """SURVEY.md §8d's formula, kept for reference: B_ray = 32*N_boxes + 48*N_tris + 32 (ray) + 16 (hit) per query, +460 B
+    per closest-hit surface fetch of the REFERENCE layout (128 MeshInfo + 12 indices + 288 vertices + 32 payload), plus
+    the per-pixel frame-buffer traffic of the pass. It prices a box test at a BVH2 node's 32 B; the shipped node holds
+    four boxes in 64 B, so this figure overstates what the kernels request (see requested_bytes)."""
     rays = c.closest_queries + c.any_queries
     b = 32 * c.boxes_tested + 48 * c.tris_tested + 48 * rays + 460 * c.closest_queries
     if which == KIND_RIS:
@@ -43,20 +61,98 @@ def algorithmic_bytes(c, n_pixels, which):
     return b
 
 
-def pmc_traffic(dom, world, W, H, grid):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/
-    r01_pmc_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 --pmc runs of this
-    very script and corrected as MI355X_MICROARCH.md §HBM prescribes). Counters cannot be read from inside
-    a normal run, so this is the profiled value for the default single-GPU workload, else null."""
-    if world != 1 or (W, H, grid) != (1920, 1080, 708):
-        return None
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+def requested_bytes(c, n_pixels, which):
+    """ALGORITHMIC bytes of one launch at the sizes of the data layout the kernels actually read:
+    16 B per box test (one 64-byte quantised node per four boxes, csrc/bvh_layout.h), 48 B per triangle test, per
+    closest hit the 48-byte shade record + 36 B WorldToObject + the 32-byte mesh constants = 116 B, and the per-pixel
+    frame-buffer traffic of the pass. Rays live in registers (no ray / hit records are read or written)."""
+    b = 16 * c.boxes_tested + 48 * c.tris_tested + 116 * c.closest_queries
+    if which == KIND_RIS:
+        b += n_pixels * (14 + 96 + 2 * 48)   # G-buffer + both reservoirs written, both history reservoirs read
+    else:
+        b += n_pixels * (16 + 9 * 48 + 9 * 6)
+    return b
+
+
+def live_pmc(argv_tail, timeout_s=150):
+    """Physical counters of THIS run's workload, measured now: one `rocprofv3 --pmc <group> -- python3 bench.py ...`
+    child per counter group (separate passes, the program itself after `--`), started before this process touches the
+    GPU. Returns {kernel: {counter: mean per launch}} plus provenance, or {"error": ...}: the bench line then carries
+    nulls instead of stale numbers."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    work = tempfile.mkdtemp(prefix="sunray_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    out = {"kernels": {}, "passes": []}
+    t0 = time.time()
     try:
-        with open(path) as fh:
-            k = json.load(fh)["kernels"]["final_kernel" if dom == KIND_FINAL else "ris_kernel"]
-        return k["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+        for gi, group in enumerate(PMC_GROUPS):
+            d = os.path.join(work, "g%d" % gi)
+            cmd = [exe, "--pmc"] + group + ["--output-format", "csv", "-d", d, "-o", "p", "--",
+                                            "python3", os.path.abspath(__file__)] + argv_tail
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return {"error": "pmc pass %s timed out after %d s" % (group, timeout_s)}
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"error": "pmc pass %s failed (rc %d): %s" % (group, r.returncode, r.stdout.decode("utf-8", "replace")[-300:])}
+            acc = {}
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        k = row["Kernel_Name"]
+                        for name in ("ris_kernel<0>", "final_kernel<0>"):
+                            if "srd::" + name in k:
+                                acc.setdefault((name[:-3], row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+            for (k, cn), v in acc.items():
+                out["kernels"].setdefault(k, {})[cn] = sum(v) / len(v)
+                out["kernels"][k]["launches_" + cn] = len(v)
+            out["passes"].append(" ".join(["rocprofv3", "--pmc"] + group + ["--", "python3", "bench.py"] + argv_tail))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    out["seconds"] = time.time() - t0
+    return out
+
+
+def git_head():
+    import subprocess
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                              timeout=10).stdout.decode().strip() or None
+    except Exception:
         return None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start `torch.distributed.run` with N ranks as a CHILD process
+    (before this process imports torch or touches the GPU: a GPU-initialised process must never exec another program),
+    relay rank 0's JSON line, exit with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    text = r.stdout.decode("utf-8", "replace")
+    lines = [ln for ln in text.splitlines() if ln.startswith('{"metric"')]
+    if lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stdout.write(text)
+    if r.returncode != 0 or not lines:
+        raise SystemExit(r.returncode or 1)
+    raise SystemExit(0)
 
 
 def cpu_baseline(desc, W, H, blue_noise, budget_s=12.0, max_frames=8):
@@ -93,7 +189,17 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--grid", type=int, default=708, help="heightfield grid: 2*(grid-1)^2 triangles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic and the hbm / valu_issue bounds become null)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)      # does not return
+
+    # Physical counters of this very workload, measured before this process touches the GPU (N = 1 only).
+    pmc = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_pmc:
+        pmc = live_pmc(["--gpus", "1", "--steps", "3", "--warmup", "3", "--no-cpu-baseline", "--no-pmc",
+                        "--width", str(args.width), "--height", str(args.height), "--grid", str(args.grid)])
 
     import numpy as np
     import torch
@@ -104,8 +210,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch --gpus %d through torch.distributed.run (one process per GPU)" % args.gpus)
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -285,10 +389,46 @@ def main():
         dom_name = "final_kernel (raytracing_final)" if dom == KIND_FINAL else "ris_kernel (raytracing_ris)"
         # with N > 1 the RIS pass is 1 strip launch + up to 2 halo launches per step: price it per step
         avg_ms = dom_ms / max(dom_n, 1) if (dom == KIND_FINAL or world == 1) else dom_ms / args.steps
-        bytes_per_launch = algorithmic_bytes(per_kind[dom], W * h, dom)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0   # SUNRAY_BENCH_TIMING=0 (tuning): no per-launch events
+        other = KIND_RIS if dom == KIND_FINAL else KIND_FINAL
+        other_ms = (ris_ms / max(ris_n, 1)) if dom == KIND_FINAL else (fin_ms / max(fin_n, 1))
         ck = per_kind[dom]
         nq = max(ck.closest_queries + ck.any_queries, 1)
+        req = requested_bytes(ck, W * h, dom)
+
+        def bounds_of(kind, ms, req_bytes):
+            """Fractions of the three rooflines a pass can be held against; each is <= 1 by construction."""
+            k = (pmc or {}).get("kernels", {}).get(KERNEL_OF[kind], {}) if pmc and "error" not in pmc else {}
+            t = ms * 1e-3
+            b = {"l2_gather": {"achieved": req_bytes / t / 1e9 if t > 0 else 0.0, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s",
+                               "what": "requested bytes (16 B per box test, 48 B per triangle test, 116 B per closest hit, frame buffers) / launch time "
+                                       "vs the L2-resident gather rate of MI355X_MICROARCH.md (16.8-18.8 TB/s)"}}
+            b["l2_gather"]["frac"] = b["l2_gather"]["achieved"] / L2_GATHER_PEAK_GBS
+            if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+                traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0   # KiB; gfx950 FETCH_SIZE counts 128-B requests at 64 B: doubled
+                b["hbm"] = {"achieved": traffic / t / 1e9 if t > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic_bytes_per_launch": traffic,
+                            "what": "physical HBM bytes per launch (live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, read side x2 as the guide prescribes "
+                                    "for gfx950) / launch time vs 8 TB/s"}
+                b["hbm"]["frac"] = b["hbm"]["achieved"] / HBM_PEAK_GBS
+            if "SQ_INSTS_VALU" in k and "GRBM_GUI_ACTIVE" in k:
+                cycles = k["GRBM_GUI_ACTIVE"] / 8.0                             # summed over the 8 XCDs
+                b["valu_issue"] = {"achieved": k["SQ_INSTS_VALU"] * 2.0 / cycles if cycles > 0 else 0.0, "peak": float(N_SIMD), "unit": "SIMD-cycles per cycle",
+                                   "what": "SQ_INSTS_VALU x 2 cycles (wave64 on a SIMD-32) / kernel cycles (GRBM_GUI_ACTIVE / 8) vs 1024 SIMDs; counters from "
+                                           "the same launch under rocprofv3 --pmc",
+                                   "lane_utilisation": k["SQ_THREAD_CYCLES_VALU"] / 64.0 / k["SQ_ACTIVE_INST_VALU"] if k.get("SQ_ACTIVE_INST_VALU") else None,
+                                   "wave_time_waiting": k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"] if k.get("SQ_WAVE_CYCLES") else None}
+                b["valu_issue"]["frac"] = b["valu_issue"]["achieved"] / N_SIMD
+            if "TCC_HIT_sum" in k and "TCC_MISS_sum" in k and (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]) > 0:
+                b["l2_gather"]["l2_hit_rate"] = k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"])
+            if "TA_TA_BUSY_sum" in k and "GRBM_GUI_ACTIVE" in k and k["GRBM_GUI_ACTIVE"] > 0:
+                b["l2_gather"]["ta_busy"] = k["TA_TA_BUSY_sum"] / 256.0 / (k["GRBM_GUI_ACTIVE"] / 8.0)
+            return b
+
+        bounds_dom = bounds_of(dom, avg_ms, req)
+        binding_name = max(bounds_dom, key=lambda n: bounds_dom[n]["frac"])
+        binding = bounds_dom[binding_name]
+        pmc_note = ("live: %d rocprofv3 --pmc passes of this workload run by this process before the timed region (%.0f s), HEAD %s"
+                    % (len(pmc["passes"]), pmc["seconds"], git_head())) if pmc and "error" not in pmc else \
+                   ("not measured: " + (pmc["error"] if pmc else "N > 1 or --no-pmc"))
         out = {
             "metric": "Mray/s (closest-hit + any-hit queries issued per second), 1920x1080, 1 spp, 1M-triangle scene",
             "value": total_rays / elapsed / 1e6,
@@ -317,22 +457,26 @@ def main():
                 "last_frame_crc32": frame_crc,
             },
             "roofline": {
-                "bound": "hbm",
+                "bound": binding_name,
                 "kernel": dom_name,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(dom, world, W, H, args.grid),
+                "achieved": binding["achieved"],
+                "peak": binding["peak"],
+                "unit": binding["unit"],
+                "frac": binding["frac"],
+                "traffic": bounds_dom.get("hbm", {}).get("traffic_bytes_per_launch"),
+                "traffic_source": pmc_note,
+                "bounds": bounds_dom,
                 "avg_launch_ms": avg_ms,
                 "launches_timed": dom_n,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "algorithmic_bytes_per_launch": req,
+                "algorithmic_bytes_per_launch_survey_formula": survey_bytes(ck, W * h, dom),
                 "boxes_per_ray": ck.boxes_tested / nq,
                 "tris_per_ray": ck.tris_tested / nq,
-                "other_pass_avg_ms": (ris_ms / max(ris_n, 1)) if dom == KIND_FINAL else (fin_ms / max(fin_n, 1)),
-                "note": "achieved = algorithmic bytes (32 B per box test actually executed, incl. speculative ones) / launch time; the node "
-                        "and triangle arrays are served mostly by L2 / Infinity Cache (`traffic` = physical HBM bytes per launch from the "
-                        "PMC counters), so frac is not bounded by 1: the pass is latency-bound, not HBM-bound (DESIGN.md section 5)",
+                "other_pass": {"kernel": KERNEL_OF[other], "avg_launch_ms": other_ms,
+                               "bounds": bounds_of(other, other_ms, requested_bytes(per_kind[other], W * h, other))},
+                "note": "three physical rooflines per pass, `bound` = the one with the largest fraction. The passes gather 64-byte BVH nodes and "
+                        "48-byte triangles that live in L2 / Infinity Cache (16.5 MB + 48 MB), so HBM is not the binding roof; none of the three "
+                        "is saturated: a node step waits for the slowest of its lanes' dependent fetches (DESIGN.md section 5)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -840,3 +840,41 @@ def test_full_size_1m_triangles_1080p(rt, oracle, blue_noise):
     assert_bits_equal(h1, gf.host()["raw_color"], "re-render")
     st = gsc.bvh_stats()
     assert st.n_triangles == 999714 and st.max_depth <= 32
+
+
+def _knobs(enable_restir, bounces):
+    cfg = abi.SrTraceConfig.reference()
+    cfg.enable_restir, cfg.max_bounces, cfg.shadow_bounces = enable_restir, bounces, bounces
+    return cfg
+
+
+def test_config2_torus_knot_1080p_diffuse_only(rt, oracle, blue_noise):
+    """BASELINE.json configs[1] at its stated workload: the 70 004-triangle torus knot (the Bunny stand-in),
+    1920x1080, 1 spp, enable_restir = 0, one bounce (primary + one NEE shadow ray; ray_gen_final.slang:40-42,135-136
+    with BOUNCES = SHADOW_BOUNCES = 1). Every pixel against the oracle, bit for bit, ray counters included."""
+    desc = scenes.torus_knot()
+    osc, gsc, of, gf = run_both(rt, oracle, desc, 1920, 1080, 1, blue_noise, _knobs(0, 1))
+    assert gsc.bvh_stats().n_triangles == 70004
+    c = gsc.counters()
+    assert c.closest_queries == 1920 * 1080 and 0 < c.any_queries <= c.closest_queries   # one primary per pixel, at most one NEE ray
+    h = gf.host()["raw_color"]
+    assert np.isfinite(h).all() and h[:, :3].any()
+
+
+def test_config3_heightfield_1080p_two_bounces_four_frames(rt, oracle, blue_noise):
+    """BASELINE.json configs[2] at its stated workload: 999 714-triangle heightfield, 1920x1080, 4 spp as frames 0..3
+    (frame_count is the per-sample seed, rt_utils.slang:47-52), enable_restir = 0, two bounces + NEE shadow rays."""
+    desc = scenes.heightfield(708)
+    osc, gsc, of, gf = run_both(rt, oracle, desc, 1920, 1080, 4, blue_noise, _knobs(0, 2))
+    assert gsc.bvh_stats().n_triangles == 999714
+    c = gsc.counters()
+    assert 1920 * 1080 < c.closest_queries <= 2 * 1920 * 1080
+
+
+def test_config4_textured_atrium_1080p_ris_and_final(rt, oracle, blue_noise):
+    """BASELINE.json configs[3] at its stated extent: the full textured atrium (248 384 triangles, 512x512 base-colour /
+    metallic-roughness / normal textures, 64 emissive triangles, 5 % mirrors), 1920x1080, reference constants
+    (raytracing_ris + raytracing_final, temporal reuse active from frame 1), three consecutive frames."""
+    desc = scenes.atrium()
+    osc, gsc, of, gf = run_both(rt, oracle, desc, 1920, 1080, 3, blue_noise)
+    assert gsc.bvh_stats().n_triangles == 248384
