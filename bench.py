@@ -234,11 +234,13 @@ def main():
     frame = rt.DeviceFrame(W, H, blue_noise, device=device)
     cfg = abi.SrTraceConfig.reference()
     import copy
+    axis = os.environ.get("SUNRAY_BENCH_AXIS", "cols")          # column strips (default) or "rows"
     bounds = None
     if world > 1:
-        # Strip boundaries of equal MEASURED cost (sky rows are far cheaper than surface rows, rows near the horizon the most
-        # expensive), from a few uncounted whole-frame frames on a throwaway frame buffer. The cut is frozen before frame 0
-        # (a rank owns the temporal history of its rows + halo); all ranks must agree on it, so rank 0's cut is broadcast.
+        # Strip boundaries of equal MEASURED cost, from a few uncounted whole-frame frames on a throwaway frame buffer: the
+        # library records every tile's cycle count for its own tile schedule. Column strips give every rank the same mix of
+        # rows (sky / horizon / foreground), so the cut only has to even out the centre-to-edge difference. The cut is
+        # frozen before frame 0 (a rank owns the temporal history of its strip + halo); rank 0's cut is broadcast.
         cal = rt.DeviceFrame(W, H, blue_noise, device=device)
         ccfg = copy.copy(cfg)
         ccfg.flags = cfg.flags | abi.TRACE_FLAG_UNCOUNTED
@@ -248,54 +250,16 @@ def main():
             cprev = list(cm.view_proj)
             scene.trace_ris(cal, cm, f, ccfg)
             scene.trace_final(cal, cm, f, ccfg)
-        # measured cycles per tile row of both passes (the data behind the library's tile schedule), spread over pixel rows
-        tile_rows = scene.tile_row_costs(0, W, 0, H) + scene.tile_row_costs(1, W, 0, H)
-        row_cost = np.repeat(tile_rows / 8.0, 8)[:H]
-        bounds = sd.balanced_bounds(row_cost, world)
-        blist = [bounds]
+        tiles_x = (W + 7) // 8
+        tile_costs = scene.tile_costs(0, W, 0, H).astype(np.float64) + scene.tile_costs(1, W, 0, H)
+        cost = sd.axis_cost_from_tiles(tile_costs, tiles_x, axis, W if axis == "cols" else H)
+        blist = [sd.balanced_bounds(cost, world, min_size=sd.SPATIAL_HALO + 2)]
         dist.broadcast_object_list(blist, src=0)      # cycle counts differ a little from GPU to GPU: take rank 0's cut
         bounds = [int(v) for v in blist[0]]
-        # Feedback rounds: a rank's share is about one round of waves, so its step time is not proportional to the cycle sum
-        # of its rows. Every rank measures its real step time with the current cut (two frames in flight, as in the timed
-        # region), rank 0 re-weights the rows of the slow ranks and cuts again; the cut with the smallest maximum is kept.
-        if os.environ.get("SUNRAY_BENCH_FEEDBACK", "1") == "1":
-            cpipe = sd.FramePipeline(cal, rt.DeviceFrame(W, H, blue_noise, device=device))
-            cstate = {"f": 4, "prev": cprev}
-
-            def cal_steps(n, b, evs=None):
-                for i in range(n):
-                    cm = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, cstate["prev"])
-                    cstate["prev"] = list(cm.view_proj)
-                    cpipe.step(scene, cm, cstate["f"], ccfg, world, rank, bounds=b,
-                               after_final=(lambda g, i=i: evs[i].record(cpipe.s_final)) if evs is not None else None)
-                    cstate["f"] += 1
-
-            best = (float("inf"), bounds)
-            for it in range(4):
-                cal_steps(4, bounds)                       # refill the temporal history of rows that changed hands
-                evs = [torch.cuda.Event(enable_timing=True) for _ in range(13)]
-                cal_steps(13, bounds, evs)
-                torch.cuda.synchronize()
-                gaps = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(12))
-                mine = torch.tensor([gaps[6]], dtype=torch.float64, device="cpu" if rehearsal else device)   # median step time
-                allp = [torch.zeros_like(mine) for _ in range(world)]
-                dist.all_gather(allp, mine)
-                periods = [float(x.item()) for x in allp]
-                if max(periods) < best[0]:
-                    best = (max(periods), bounds)
-                if it == 3:
-                    break
-                blist = [None]
-                if rank == 0:
-                    row_cost, nb = sd.refine_bounds(row_cost, bounds, periods)
-                    blist = [nb]
-                dist.broadcast_object_list(blist, src=0)
-                bounds = [int(v) for v in blist[0]]
-            bounds = best[1]
-            del cpipe
         del cal
+    part = sd.Partition(W, H, world, axis, bounds)
     # the gather of frame f overlaps the tracing of frame f+1 (RCCL runs on its own stream); rehearsal: gloo on host copies
-    pipe = sd.GatherPipeline(W, H, world, rank, "cpu" if rehearsal else device, bounds=bounds) if world > 1 else None
+    pipe = sd.GatherPipeline(part, rank, "cpu" if rehearsal else device) if world > 1 else None
 
     state = {"prev": None, "frame": 0, "last": frame}
     # Two frames in flight per GPU (RIS of frame f+1 overlaps the draining final pass of frame f): a rank's share of a frame
@@ -316,9 +280,9 @@ def main():
         m = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, state["prev"])
         state["prev"] = list(m.view_proj)
         if fpipe is not None:
-            state["last"] = fpipe.step(scene, m, state["frame"], cfg, world, rank, bounds=bounds, after_final=submit_gather)
+            state["last"] = fpipe.step(scene, m, state["frame"], cfg, part, rank, after_final=submit_gather)
         else:
-            sd.render_strip(scene, frame, m, state["frame"], cfg, world, rank, abi.TRACE_FLAG_UNCOUNTED, bounds=bounds)
+            sd.render_strip(scene, frame, m, state["frame"], cfg, part, rank)
             submit_gather(frame)
         state["frame"] += 1
 
@@ -336,18 +300,22 @@ def main():
     scene.set_instrumented(True)
     per_kind = {}
     m_i = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, state["prev"])
-    y0, h = (bounds[rank], bounds[rank + 1] - bounds[rank]) if bounds is not None else sd.strip_rows(H, world, rank)
+    a0, an = part.span(rank)
+    own = part.tile(a0, an)
+    n_own_pixels = an * (H if axis == "cols" else W)
     halo_cfg = copy.copy(cfg)
     halo_cfg.flags = cfg.flags | abi.TRACE_FLAG_UNCOUNTED
     iframe = fpipe.frames[state["frame"] & 1] if fpipe is not None else frame
     scene.reset_counters()
-    scene.trace_ris(iframe, m_i, state["frame"], cfg, tile=(y0, h))
+    scene.trace_ris(iframe, m_i, state["frame"], cfg, tile=own)
     per_kind[KIND_RIS] = scene.counters()
-    if world > 1:   # keep the halo rows' reservoirs current: they are next frame's temporal history
-        for band in sd.halo_bands(H, y0, h):
-            scene.trace_ris(iframe, m_i, state["frame"], halo_cfg, tile=band)
+    if world > 1:   # keep the halo's reservoirs current: they are next frame's temporal history
+        g0, gn = part.grown(rank, sd.SPATIAL_HALO)
+        for b0, bn in ((g0, a0 - g0), (a0 + an, g0 + gn - (a0 + an))):
+            if bn > 0:
+                scene.trace_ris(iframe, m_i, state["frame"], halo_cfg, tile=part.tile(b0, bn))
     scene.reset_counters()
-    scene.trace_final(iframe, m_i, state["frame"], cfg, tile=(y0, h))
+    scene.trace_final(iframe, m_i, state["frame"], cfg, tile=own)
     per_kind[KIND_FINAL] = scene.counters()
     state["prev"] = list(m_i.view_proj)
     state["frame"] += 1
@@ -393,7 +361,7 @@ def main():
         other_ms = (ris_ms / max(ris_n, 1)) if dom == KIND_FINAL else (fin_ms / max(fin_n, 1))
         ck = per_kind[dom]
         nq = max(ck.closest_queries + ck.any_queries, 1)
-        req = requested_bytes(ck, W * h, dom)
+        req = requested_bytes(ck, n_own_pixels, dom)
 
         def bounds_of(kind, ms, req_bytes):
             """Fractions of the three rooflines a pass can be held against; each is <= 1 by construction."""
@@ -449,8 +417,10 @@ def main():
                 "rays_per_frame": total_rays / args.steps,
                 "closest_per_frame": total_closest / args.steps,
                 "any_per_frame": total_any / args.steps,
-                "parallelism": ("rows split into %d cost-balanced strips %s, RIS halo %d rows recomputed, radiance strips all-gathered over RCCL "
-                                "asynchronously (frame f's gather overlaps frame f+1)" % (world, [bounds[i + 1] - bounds[i] for i in range(world)], sd.SPATIAL_HALO))
+                "parallelism": ("%s split into %d cost-balanced strips %s, RIS pass over strip + %d-pixel halo (recomputed, uncounted), radiance "
+                                "strips all-gathered over RCCL asynchronously (frame f's gather overlaps frame f+1); static camera, so no "
+                                "temporal-history exchange (distributed.exchange_history, motion_halo = 0)"
+                                % ("columns" if axis == "cols" else "rows", world, part.sizes(), sd.SPATIAL_HALO))
                                if world > 1 else "single GPU",
                 "frames_in_flight": 2 if pipelined else 1,
                 "bvh_build_ms_host": st.build_ms,
@@ -469,11 +439,11 @@ def main():
                 "avg_launch_ms": avg_ms,
                 "launches_timed": dom_n,
                 "algorithmic_bytes_per_launch": req,
-                "algorithmic_bytes_per_launch_survey_formula": survey_bytes(ck, W * h, dom),
+                "algorithmic_bytes_per_launch_survey_formula": survey_bytes(ck, n_own_pixels, dom),
                 "boxes_per_ray": ck.boxes_tested / nq,
                 "tris_per_ray": ck.tris_tested / nq,
                 "other_pass": {"kernel": KERNEL_OF[other], "avg_launch_ms": other_ms,
-                               "bounds": bounds_of(other, other_ms, requested_bytes(per_kind[other], W * h, other))},
+                               "bounds": bounds_of(other, other_ms, requested_bytes(per_kind[other], n_own_pixels, other))},
                 "note": "three physical rooflines per pass, `bound` = the one with the largest fraction. The passes gather 64-byte BVH nodes and "
                         "48-byte triangles that live in L2 / Infinity Cache (16.5 MB + 48 MB), so HBM is not the binding roof; none of the three "
                         "is saturated: a node step waits for the slowest of its lanes' dependent fetches (DESIGN.md section 5)",

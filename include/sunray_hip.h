@@ -195,6 +195,8 @@ typedef struct SrTraceConfig {
     uint32_t flags;           /* SR_TRACE_FLAG_* */
     uint32_t count_y0;        /* with count_rows != 0: only pixels of rows [count_y0, count_y0 + count_rows) add  */
     uint32_t count_rows;      /* their rays to the scene's counters — a strip traced together with its halo rows  */
+    uint32_t count_x0;        /* same for columns: with count_cols != 0 only pixels of columns                    */
+    uint32_t count_cols;      /* [count_x0, count_x0 + count_cols) count (column strips)              */
 } SrTraceConfig;
 
 /* Do not add this launch's rays to the scene's ray counters: used for the halo rows a GPU re-traces
@@ -235,8 +237,9 @@ typedef struct SrRtParams {
     uint32_t width, height;          /* trace_extent[0], [1]; also the image size */
     /* Sub-rectangle of the image this launch covers, for tile-parallel multi-GPU.
      * Pixels are keyed by their GLOBAL coordinates (RNG, camera), so any tiling gives identical
-     * values. tile_h == 0 means the whole image. Buffers are always full-size W*H. */
+     * values. tile_h == 0 means all rows, tile_w == 0 all columns. Buffers are always full-size W*H. */
     uint32_t tile_y0, tile_h;
+    uint32_t tile_x0, tile_w;
     SrTraceConfig config;
 } SrRtParams;
 
@@ -588,7 +591,7 @@ static_assert(sizeof(SrMatrices) == 256, "T6");
 static_assert(sizeof(SrReservoir) == 48 && sizeof(SrReservoirGI) == 48, "T7");
 static_assert(sizeof(SrRayPayload) == 32, "T8");
 static_assert(sizeof(SrRay) == 32 && sizeof(SrHit) == 16, "ray/hit");
-static_assert(sizeof(SrTraceConfig) == 32 && sizeof(SrRtParams) == 160, "T9");
+static_assert(sizeof(SrTraceConfig) == 40 && sizeof(SrRtParams) == 176, "T9");
 static_assert(sizeof(SrPostParams) == 104, "post params");
 #endif
 

@@ -222,8 +222,10 @@ class OracleScene:
         p.frame_count = frame_count
         p.use_srgb = 0
         p.width, p.height = frame.width, frame.height
-        if tile:
-            p.tile_y0, p.tile_h = tile
+        if tile:                      # (y0, h) rows, or (y0, h, x0, w) rows x columns; h == 0 / w == 0: all of them
+            p.tile_y0, p.tile_h = tile[0], tile[1]
+            if len(tile) == 4:
+                p.tile_x0, p.tile_w = tile[2], tile[3]
         p.config = config
         return p
 

@@ -605,6 +605,8 @@ template <typename F>
 void run_pass(Scene& s, const SrRtParams& p, F pixel_fn) {
     uint32_t y0 = p.tile_h ? p.tile_y0 : 0, y1 = p.tile_h ? p.tile_y0 + p.tile_h : p.height;
     if (y1 > p.height) y1 = p.height;
+    uint32_t x0 = p.tile_w ? p.tile_x0 : 0, x1 = p.tile_w ? p.tile_x0 + p.tile_w : p.width;
+    if (x1 > p.width) x1 = p.width;
     Counters total;
 #pragma omp parallel
     {
@@ -612,12 +614,16 @@ void run_pass(Scene& s, const SrRtParams& p, F pixel_fn) {
         Counters mine;
 #pragma omp for schedule(dynamic, 1)
         for (int64_t y = y0; y < (int64_t)y1; y++) {
-            cx.c = Counters{};
-            for (uint32_t x = 0; x < p.width; x++) pixel_fn(cx, x, (uint32_t)y);
-            // SR_TRACE_FLAG_UNCOUNTED / count_y0, count_rows: halo rows do not count (include/sunray_hip.h)
-            const bool counted = !(p.config.flags & SR_TRACE_FLAG_UNCOUNTED) &&
-                                 (p.config.count_rows == 0u || ((uint32_t)y - p.config.count_y0) < p.config.count_rows);
-            if (counted) { mine.closest += cx.c.closest; mine.any += cx.c.any; mine.boxes += cx.c.boxes; mine.tris += cx.c.tris; }
+            // SR_TRACE_FLAG_UNCOUNTED / count_y0, count_rows, count_x0, count_cols: halo pixels do not count (include/sunray_hip.h)
+            const bool row_counted = !(p.config.flags & SR_TRACE_FLAG_UNCOUNTED) &&
+                                     (p.config.count_rows == 0u || ((uint32_t)y - p.config.count_y0) < p.config.count_rows);
+            for (uint32_t x = x0; x < x1; x++) {
+                cx.c = Counters{};
+                pixel_fn(cx, x, (uint32_t)y);
+                if (row_counted && (p.config.count_cols == 0u || (x - p.config.count_x0) < p.config.count_cols)) {
+                    mine.closest += cx.c.closest; mine.any += cx.c.any; mine.boxes += cx.c.boxes; mine.tris += cx.c.tris;
+                }
+            }
         }
 #pragma omp critical
         { total.closest += mine.closest; total.any += mine.any; total.boxes += mine.boxes; total.tris += mine.tris; }

@@ -53,12 +53,12 @@ class SrMatrices(C.Structure):  # T6, 256 B; every float[16] = 4 rows
 class SrTraceConfig(C.Structure):
     _fields_ = [("max_bounces", C.c_uint32), ("shadow_bounces", C.c_uint32), ("ris_candidates", C.c_uint32),
                 ("virtual_bounces", C.c_uint32), ("enable_restir", C.c_uint32), ("flags", C.c_uint32),
-                ("count_y0", C.c_uint32), ("count_rows", C.c_uint32)]
+                ("count_y0", C.c_uint32), ("count_rows", C.c_uint32), ("count_x0", C.c_uint32), ("count_cols", C.c_uint32)]
 
     @staticmethod
     def reference():
         """The reference's compile-time constants (ray_gen_final.slang:40-42, ray_gen_ris.slang:69,187)."""
-        return SrTraceConfig(10, 5, 16, 20, 1, 0, 0, 0)
+        return SrTraceConfig(10, 5, 16, 20, 1, 0, 0, 0, 0, 0)
 
 
 class SrRtParams(C.Structure):  # T9
@@ -69,7 +69,7 @@ class SrRtParams(C.Structure):  # T9
                 ("reservoirs", C.c_void_p * 2), ("reservoirs_gi", C.c_void_p * 2),
                 ("frame_count", C.c_uint32), ("use_srgb", C.c_uint32),
                 ("width", C.c_uint32), ("height", C.c_uint32), ("tile_y0", C.c_uint32), ("tile_h", C.c_uint32),
-                ("config", SrTraceConfig)]
+                ("tile_x0", C.c_uint32), ("tile_w", C.c_uint32), ("config", SrTraceConfig)]
 
 
 class SrPostParams(C.Structure):  # post-RT compute chain (temporal accumulation, a-trous denoise, tonemap)

@@ -85,7 +85,7 @@ struct SrScene {
     // acceleration-structure maintenance (update in place): per-level node lists, exact node boxes, flatten inputs
     DeviceBuffer d_level_nodes, d_node_box, d_mesh_infos, d_flat_instances, d_scratch;
     // cost-ordered tile schedules of the two passes (kernels.hip thread_pixel), one per launch geometry
-    struct TileSchedule { int which = -1; uint32_t width = 0, y0 = 0, y1 = 0; DeviceBuffer cost, order; bool have_order = false; uint64_t last_use = 0; uint32_t uses = 0; };
+    struct TileSchedule { int which = -1; uint32_t width = 0 /* columns of the launch rectangle */, y0 = 0, y1 = 0, x0 = 0; DeviceBuffer cost, order; bool have_order = false; uint64_t last_use = 0; uint32_t uses = 0; };
     std::vector<TileSchedule> schedules;
     uint64_t schedule_clock = 0;
     int tile_scheduling = 1;                // SR_TILE_SCHEDULING=0 in the environment disables it (A/B)
@@ -777,6 +777,13 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
         y0 = p->tile_y0;
         y1 = std::min(p->height, p->tile_y0 + p->tile_h);
     }
+    uint32_t x0 = 0, x1 = p->width;
+    if (p->tile_w) {
+        if (p->tile_x0 >= p->width) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": tile outside the image");
+        x0 = p->tile_x0;
+        x1 = std::min(p->width, p->tile_x0 + p->tile_w);
+    }
+    const uint32_t cols = x1 - x0;
     int rc = bind_device(s);
     if (rc != SR_OK) return rc;
     srd::PassArgs a;
@@ -790,22 +797,22 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
     a.reservoirs_gi[0] = p->reservoirs_gi[0]; a.reservoirs_gi[1] = p->reservoirs_gi[1];
     a.frame_count = p->frame_count;
     a.width = p->width; a.height = p->height;
-    a.y0 = y0; a.y1 = y1;
+    a.y0 = y0; a.y1 = y1; a.x0 = x0; a.x1 = x1;
     a.cfg = p->config;
     hipStream_t st = (hipStream_t)stream;
     // tile schedule of this launch geometry: order from the previous launch's costs, costs of this launch for the next
     SrScene::TileSchedule* sched = nullptr;
     if (s->tile_scheduling) {
-        for (auto& ts : s->schedules) if (ts.which == which && ts.width == p->width && ts.y0 == y0 && ts.y1 == y1) sched = &ts;
+        for (auto& ts : s->schedules) if (ts.which == which && ts.width == cols && ts.x0 == x0 && ts.y0 == y0 && ts.y1 == y1) sched = &ts;
         if (!sched) {
             if (s->schedules.size() < 8) s->schedules.emplace_back();
             sched = &s->schedules[0];
             for (auto& ts : s->schedules) if (ts.which < 0 || ts.last_use < sched->last_use) sched = &ts;
             if (sched->which >= 0) HIP_TRY(hipStreamSynchronize(st));          // recycling an entry a launch may still read
-            const size_t bytes = (size_t)srk_pass_tile_count(p->width, y1 - y0) * 4;
-            if ((rc = sched->cost.reserve(bytes)) != SR_OK || (rc = sched->order.reserve((size_t)srk_pass_order_cap(p->width, y1 - y0) * 8 * 4)) != SR_OK) return rc;
+            const size_t bytes = (size_t)srk_pass_tile_count(cols, y1 - y0) * 4;
+            if ((rc = sched->cost.reserve(bytes)) != SR_OK || (rc = sched->order.reserve((size_t)srk_pass_order_cap(cols, y1 - y0) * 8 * 4)) != SR_OK) return rc;
             HIP_TRY(hipMemsetAsync(sched->cost.p, 0, bytes, st));
-            sched->which = which; sched->width = p->width; sched->y0 = y0; sched->y1 = y1; sched->have_order = false; sched->uses = 0;
+            sched->which = which; sched->width = cols; sched->x0 = x0; sched->y0 = y0; sched->y1 = y1; sched->have_order = false; sched->uses = 0;
         }
         sched->last_use = ++s->schedule_clock;
         a.tile_cost = (uint32_t*)sched->cost.p;
@@ -820,7 +827,7 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
     // The sweep direction changes rarely (it follows where the expensive rows are): re-derive it after the first launches
     // of a geometry and then every 16th, not after every launch (a 9 us kernel plus its launch gap per pass).
     if (sched && (sched->uses++ < 4 || (sched->uses & 15u) == 0u)) {
-        e = srk_launch_tile_order((const uint32_t*)sched->cost.p, (uint32_t*)sched->order.p, p->width, y1 - y0, st);
+        e = srk_launch_tile_order((const uint32_t*)sched->cost.p, (uint32_t*)sched->order.p, cols, y1 - y0, st);
         if (e != 0) return fail(SR_ERR_HIP, std::string(name) + " tile schedule: " + hipGetErrorString((hipError_t)e));
         sched->have_order = true;
     }
@@ -832,7 +839,7 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
 int sr_scene_read_tile_row_costs(SrScene* s, int which, uint32_t width, uint32_t y0, uint32_t rows, double* out, uint32_t cap, uint32_t* n_tile_rows) {
     if (!s || !out || !n_tile_rows) return fail(SR_ERR_INVALID_ARG, "sr_scene_read_tile_row_costs: null argument");
     SrScene::TileSchedule* sched = nullptr;
-    for (auto& ts : s->schedules) if (ts.which == which && ts.width == width && ts.y0 == y0 && ts.y1 == y0 + rows) sched = &ts;
+    for (auto& ts : s->schedules) if (ts.which == which && ts.width == width && ts.x0 == 0 && ts.y0 == y0 && ts.y1 == y0 + rows) sched = &ts;
     if (!sched) return fail(SR_ERR_STATE, "sr_scene_read_tile_row_costs: no launch of this pass with this geometry yet");
     int rc = bind_device(s);
     if (rc != SR_OK) return rc;
@@ -855,7 +862,7 @@ int sr_scene_read_tile_row_costs(SrScene* s, int which, uint32_t width, uint32_t
 int sr_scene_read_tile_costs(SrScene* s, int which, uint32_t width, uint32_t y0, uint32_t rows, uint32_t* out, uint32_t cap, uint32_t* n_tiles_out) {
     if (!s || !out || !n_tiles_out) return fail(SR_ERR_INVALID_ARG, "sr_scene_read_tile_costs: null argument");
     SrScene::TileSchedule* sched = nullptr;
-    for (auto& ts : s->schedules) if (ts.which == which && ts.width == width && ts.y0 == y0 && ts.y1 == y0 + rows) sched = &ts;
+    for (auto& ts : s->schedules) if (ts.which == which && ts.width == width && ts.x0 == 0 && ts.y0 == y0 && ts.y1 == y0 + rows) sched = &ts;
     if (!sched) return fail(SR_ERR_STATE, "sr_scene_read_tile_costs: no launch of this pass with this geometry yet");
     const uint32_t n_tiles = srk_pass_tile_count(width, rows);
     *n_tiles_out = n_tiles;

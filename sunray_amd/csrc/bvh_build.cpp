@@ -435,11 +435,7 @@ void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult&
     }
     res.nodes2.swap(top.nodes);
     res.sah_cost = (float)top.cost;
-#ifdef SR_STACK_BUDGET
-    collapse_to_bvh4(res, (uint32_t)SR_STACK_BUDGET);   // experiment: a stack budget above the binary depth bound
-#else
     collapse_to_bvh4(res, max_depth);
-#endif
     res.order = b.order;
     res.tris.resize((size_t)n * 12);
     for (uint32_t i = 0; i < n; i++) {

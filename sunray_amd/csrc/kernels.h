@@ -22,8 +22,9 @@ struct PassArgs {
     SrReservoirGI* reservoirs_gi[2];
     uint32_t frame_count;
     uint32_t width, height;
-    uint32_t y0, y1;              // rows [y0, y1) of the image are traced by this launch
-    uint32_t tiles_x, tiles_y;    // pixel tiles covering width x (y1 - y0); filled in by srk_launch_pass
+    uint32_t y0, y1;              // rows [y0, y1) and
+    uint32_t x0, x1;              // columns [x0, x1) of the image are traced by this launch
+    uint32_t tiles_x, tiles_y;    // pixel tiles covering (x1 - x0) x (y1 - y0); filled in by srk_launch_pass
     uint32_t order_cap;           // blocks per XCD = entries per XCD in tile_order (srk_pass_order_cap)
     // cost-ordered tile schedule (kernels.hip): this launch's per-tile cost is written to tile_cost, the order derived
     // from the PREVIOUS launch's costs is read from tile_order (null on the first launch of a geometry)

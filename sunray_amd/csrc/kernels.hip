@@ -16,27 +16,10 @@
 namespace srd {
 
 constexpr int kBlock = 256;        // ray-queue and shade kernels
-#ifndef SR_PASS_BLOCK
-#define SR_PASS_BLOCK 64
-#endif
-constexpr int kPassBlock = SR_PASS_BLOCK;                 // the two pass megakernels: one wave = one 8x8 pixel tile
-constexpr int kPassTile = kPassBlock == 256 ? 16 : 8;     // (256 threads: 16x16 tile of four 8x8 wave tiles)
-#ifndef SR_WORK_STEALING
-#define SR_WORK_STEALING 1        // 1: lanes that finish their ray early take over subtrees of the wave's busy lanes (traverse_ws)
-#endif
-#ifndef SR_LDS_PAD_ROWS
-#define SR_LDS_PAD_ROWS 0         // experiment hook: unused LDS rows (isolates the occupancy effect of a deeper stack)
-#endif
-constexpr int kLdsExtraRows = ((SR_WORK_STEALING && SR_BVH_WIDTH != 8) ? kWsRows : 0) + SR_LDS_PAD_ROWS;
-#ifndef SR_FLAT_FINAL
-#define SR_FLAT_FINAL 1           // 1 (with SR_WORK_STEALING): predicated form of the final pass, all lanes reach every trace point
-#endif
-#ifndef SR_RIS_WAVES
-#define SR_RIS_WAVES 4
-#endif
-#ifndef SR_FINAL_WAVES
-#define SR_FINAL_WAVES 4
-#endif                                                    // __launch_bounds__ second argument on HIP: waves per SIMD (4 -> VGPR budget 128)
+constexpr int kPassBlock = 64;     // the two pass megakernels: one wave = one workgroup = one 8x8 pixel tile
+constexpr int kPassTile = 8;
+constexpr int kLdsExtraRows = kWsRows;   // LDS rows of the work-stealing traversal in front of the stack levels
+constexpr int kPassWaves = 4;      // __launch_bounds__ second argument on HIP: waves per SIMD (4 -> VGPR budget 128)
 
 // Wave-wide sum, then one atomic per wave (rays are counted, not estimated: SURVEY.md §8d).
 SRD void flush_counter(unsigned long long* dst, uint32_t v) {
@@ -63,7 +46,6 @@ __global__ __launch_bounds__(kBlock) void trace_queue_kernel(DevScene sc, const 
         base = __shfl(base, 0);
         if (base >= n) break;  // wave-uniform exit: every wave reaches it once the queue is drained
         const uint32_t i = base + lane;
-#if SR_WORK_STEALING && SR_BVH_WIDTH != 8
         {
             const uint32_t ic = i < n ? i : n - 1u;
             const float4 ra = reinterpret_cast<const float4*>(rays)[ic * 2 + 0];
@@ -71,14 +53,6 @@ __global__ __launch_bounds__(kBlock) void trace_queue_kernel(DevScene sc, const 
             TravHit h;
             const bool found = traverse_ws<ANY, STATS>(sc, i < n, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), ra.w, rb.w, h, stack, kBlock, st);
             if (i < n) {
-#else
-        if (i < n) {
-            const float4 ra = reinterpret_cast<const float4*>(rays)[i * 2 + 0];
-            const float4 rb = reinterpret_cast<const float4*>(rays)[i * 2 + 1];
-            TravHit h;
-            const bool found = traverse<ANY, STATS>(sc, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), ra.w, rb.w, h, stack, kBlock, st);
-            {
-#endif
             n_queries++;
             if (ANY) occluded[i] = found ? 1u : 0u;
             else {
@@ -138,11 +112,7 @@ struct PixelCtx {
 template <int V>
 SRD Payload trace_closest_shaded(PixelCtx& cx, f3 o, f3 d, float tmin, float tmax) {
     TravHit h;
-#if SR_WORK_STEALING && SR_BVH_WIDTH != 8
     traverse_ws<false, (V & 1) != 0>(cx.a.sc, true, o, d, tmin, tmax, h, cx.stack, kPassBlock, cx.st);
-#else
-    traverse<false, (V & 1) != 0>(cx.a.sc, o, d, tmin, tmax, h, cx.stack, kPassBlock, cx.st);
-#endif
     cx.n_closest++;
     return shade_hit<(V & 2) != 0>(cx.a.sc, h);
 }
@@ -153,11 +123,7 @@ SRD float trace_shadow(PixelCtx& cx, f3 o, f3 d, float dist) {
     if (dist > 0.002f) {
         TravHit h;
         cx.n_any++;
-#if SR_WORK_STEALING && SR_BVH_WIDTH != 8
         return traverse_ws<true, (V & 1) != 0>(cx.a.sc, true, o, d, 0.001f, dist - 0.001f, h, cx.stack, kPassBlock, cx.st) ? 1.0f : -1.0f;
-#else
-        return traverse<true, (V & 1) != 0>(cx.a.sc, o, d, 0.001f, dist - 0.001f, h, cx.stack, kPassBlock, cx.st) ? 1.0f : -1.0f;
-#endif
     }
     return -1.0f;
 }
@@ -245,18 +211,14 @@ SRD bool thread_pixel(const PassArgs& a, uint32_t& px, uint32_t& py, uint32_t& c
     if (tile >= a.tiles_x * a.tiles_y) return false;
     cost_slot = tile;
     const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
-    px = tx * (uint32_t)kPassTile + (w & 1u) * 8u + (l & 7u);
-    py = a.y0 + ty * (uint32_t)kPassTile + (w >> 1) * 8u + (l >> 3);
-    return px < a.width && py < a.y1;
+    const uint32_t l = threadIdx.x;
+    px = a.x0 + tx * (uint32_t)kPassTile + (l & 7u);
+    py = a.y0 + ty * (uint32_t)kPassTile + (l >> 3);
+    return px < a.x1 && py < a.y1;
 }
 SRD void record_tile_cost(const PassArgs& a, uint32_t cost_slot, unsigned long long t_start) {
     if (a.tile_cost && cost_slot != 0xFFFFFFFFu && threadIdx.x == 0) {
         const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
-#if SR_DIAG_TIMELINE   // diagnostics (scripts/gpu_wave_timeline.py): in frame SR_DIAG_TIMELINE the slot holds the wave's END time on the
-                       // device-wide 100 MHz counter (20 bits) << 12 | its duration in units of 256 shader cycles
-        if (a.frame_count == SR_DIAG_TIMELINE) { a.tile_cost[cost_slot] = (uint32_t)((__builtin_amdgcn_s_memrealtime() & 0xFFFFFull) << 12) | (uint32_t)min(dt >> 8, 0xFFFull); return; }
-#endif
         a.tile_cost[cost_slot] = (uint32_t)(dt > 0xFFFFFFFFull ? 0xFFFFFFFFull : dt);
     }
 }
@@ -364,7 +326,6 @@ __global__ void tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* _
     }
 }
 
-#if SR_WORK_STEALING && SR_BVH_WIDTH != 8
 // One query of the flattened passes: reached by every lane of the wave, `want` = this lane has a ray (counted as the
 // TraceRay it stands for). Returns found / occluded for the lane's own ray.
 template <int V, bool ANY>
@@ -372,10 +333,9 @@ SRD bool ws_query(PixelCtx& cx, bool want, f3 o, f3 d, float tmin, float tmax, T
     if (want) { if (ANY) cx.n_any++; else cx.n_closest++; }
     return traverse_ws<ANY, (V & 1) != 0>(cx.a.sc, want, o, d, tmin, tmax, h, cx.stack, kPassBlock, cx.st);
 }
-#endif
 
 template <int V>
-__global__ __launch_bounds__(kPassBlock, SR_RIS_WAVES) void ris_kernel(const PassArgs a) {
+__global__ __launch_bounds__(kPassBlock, kPassWaves) void ris_kernel(const PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kPassBlock], sized at launch
     PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
     const DevScene& sc = a.sc;
@@ -610,15 +570,15 @@ __global__ __launch_bounds__(kPassBlock, SR_RIS_WAVES) void ris_kernel(const Pas
     }
     record_tile_cost(a, cost_slot, t_start);
     if (!(a.cfg.flags & SR_TRACE_FLAG_UNCOUNTED)) {
-        const bool counted = a.cfg.count_rows == 0u || (py - a.cfg.count_y0) < a.cfg.count_rows;   // per lane: its pixel's row
+        const bool counted = (a.cfg.count_rows == 0u || (py - a.cfg.count_y0) < a.cfg.count_rows) &&      // per lane: its pixel's row
+                             (a.cfg.count_cols == 0u || (px - a.cfg.count_x0) < a.cfg.count_cols);       // and column
         flush_counter(sc.counters + 0, counted ? cx.n_closest : 0u);
         flush_counter(sc.counters + 1, counted ? cx.n_any : 0u);
         if (V & 1) { flush_counter(sc.counters + 2, counted ? cx.st.boxes : 0u); flush_counter(sc.counters + 3, counted ? cx.st.tris : 0u); }
     }
 }
-#if SR_WORK_STEALING && SR_BVH_WIDTH != 8 && SR_FLAT_FINAL
 template <int V>
-__global__ __launch_bounds__(kPassBlock, SR_FINAL_WAVES) void final_kernel(const PassArgs a) {
+__global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const PassArgs a) {
     // Flattened form of the pass for the work-stealing traversal: every trace point is reached by ALL lanes of the wave
     // (the control flow around it is predicated, not branched), so lanes without a ray of their own can take over
     // subtrees of the lanes that have one. Same operations in the same order per pixel as the branched form.
@@ -952,282 +912,13 @@ __global__ __launch_bounds__(kPassBlock, SR_FINAL_WAVES) void final_kernel(const
     }
     record_tile_cost(a, cost_slot, t_start);
     if (!(a.cfg.flags & SR_TRACE_FLAG_UNCOUNTED)) {
-        const bool counted = a.cfg.count_rows == 0u || (py - a.cfg.count_y0) < a.cfg.count_rows;   // per lane: its pixel's row
+        const bool counted = (a.cfg.count_rows == 0u || (py - a.cfg.count_y0) < a.cfg.count_rows) &&      // per lane: its pixel's row
+                             (a.cfg.count_cols == 0u || (px - a.cfg.count_x0) < a.cfg.count_cols);       // and column
         flush_counter(sc.counters + 0, counted ? cx.n_closest : 0u);
         flush_counter(sc.counters + 1, counted ? cx.n_any : 0u);
         if (V & 1) { flush_counter(sc.counters + 2, counted ? cx.st.boxes : 0u); flush_counter(sc.counters + 3, counted ? cx.st.tris : 0u); }
     }
 }
-#else
-template <int V>
-__global__ __launch_bounds__(kPassBlock, SR_FINAL_WAVES) void final_kernel(const PassArgs a) {
-    extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kPassBlock], sized at launch
-    PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
-    const DevScene& sc = a.sc;
-    uint32_t px = 0, py = 0, cost_slot = 0;
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-    const bool active = thread_pixel(a, px, py, cost_slot);
-    if (active) {
-        const uint32_t W = a.width, H = a.height;
-        const uint32_t pix = py * W + px;
-        const int ipx = (int)px, ipy = (int)py;
-        const uint32_t cur_buf = a.frame_count & 1u;
-        const SrReservoir* reservoir_cur = a.reservoirs[cur_buf];
-        const SrReservoirGI* reservoir_gi_cur = a.reservoirs_gi[cur_buf];
-
-        uint32_t rng = init_rng(px, py, a.frame_count, W);
-        f3 total_radiance = splat(0.0f);
-        const int BOUNCES = (int)a.cfg.max_bounces;
-        const int SHADOW_BOUNCES = (int)a.cfg.shadow_bounces;
-        const int bw = (int)a.blue_noise_w, bh = (int)a.blue_noise_h;
-        const int n1x = ipx % bw, n1y = ipy % bh;
-        const int n2x = (ipx + 47) % bw, n2y = (ipy + 71) % bh;
-        const float bn_1 = (float)a.blue_noise_tex[((size_t)n1y * bw + n1x) * 4] / 255.0f;
-        const float bn_2 = (float)a.blue_noise_tex[((size_t)n2y * bw + n2x) * 4] / 255.0f;
-        const uint32_t num_lights = sc.num_lights;
-        Payload prd;
-
-        {   // SAMPLES = 1 (ray_gen_final.slang:40)
-            f3 origin, rayDir0; f2 inUV;
-            primary_ray(a.mats, px, py, W, H, origin, rayDir0, inUV);
-            f3 rayOrigin = origin, rayDir = rayDir0;
-            f3 throughput = splat(1.0f), radiance = splat(0.0f);
-            bool restir_evaluated = (a.cfg.enable_restir == 0);
-            bool prev_did_nee = false;
-
-            for (int bounce = 0; bounce < BOUNCES; bounce++) {
-                prd = trace_closest_shaded<V>(cx, rayOrigin, rayDir, 0.001f, 10000.0f);
-                if (prd.dist < 0.0f) break;
-                const f3 hit_normal = unpack_normal(prd.normal_packed);
-                const f3 hit_albedo = unpack_unorm_rgb(prd.albedo_packed);
-                const f3 hitPos = rayOrigin + rayDir * prd.dist;
-                const f3 V_view = -rayDir;
-                const f2 mat_info = unpack_half_2x16(prd.material_info);
-                const float roughness = fmaxf(mat_info.x, 0.01f);
-                const float metallic = clampf(mat_info.y, 0.0f, 1.0f);
-                const f2 trans_ior = unpack_half_2x16(prd.transmission_ior_packed);
-                const float transmission = trans_ior.x;
-                const float ior = fmaxf(trans_ior.y, 1.0f);
-                if (!prev_did_nee) radiance = radiance + prd.emission * throughput;
-                prev_did_nee = false;
-                const float brightness = maxc(prd.emission);
-                if (brightness > 1.0f) break;
-
-                if (transmission > 0.5f) {
-                    const bool is_inside = dot3(rayDir, hit_normal) > 0.0f;
-                    const f3 N = is_inside ? -hit_normal : hit_normal;
-                    const float eta = is_inside ? (ior / 1.0f) : (1.0f / ior);
-                    const float cos_theta = fminf(dot3(-rayDir, N), 1.0f);
-                    float R0 = (1.0f - eta) / (1.0f + eta);
-                    R0 = R0 * R0;
-                    float fresnel = R0 + (1.0f - R0) * pow5f(1.0f - cos_theta);
-                    const f3 refracted = refract3(rayDir, N, eta);
-                    if (len3(refracted) < 0.01f) fresnel = 1.0f;
-                    if (rnd(rng) < fresnel) rayDir = reflect3(rayDir, N);
-                    else {
-                        rayDir = refracted;
-                        if (is_inside) {
-                            const f3 absorption = 1.0f - hit_albedo;
-                            const f3 e = -absorption * prd.dist * 5.0f;
-                            throughput = throughput * mk3(exp_pinned(e.x), exp_pinned(e.y), exp_pinned(e.z));
-                        } else throughput = throughput * hit_albedo;
-                    }
-                    rayOrigin = hitPos + rayDir * 0.001f;
-                    continue;
-                }
-
-                if (num_lights > 0 && bounce < SHADOW_BOUNCES) {
-                    if (!restir_evaluated && roughness > 0.2f) {
-                        restir_evaluated = true;
-                        SrReservoir center_r = load48(reservoir_cur + pix);
-                        SrReservoir spatial_r; zero_reservoir(spatial_r);
-                        if (center_r.W > 0.0f && center_r.light_idx < num_lights) {
-                            center_r.light_idx = center_r.light_idx < num_lights - 1 ? center_r.light_idx : num_lights - 1;
-                            const f3 fc = eval_unshadowed_light(hitPos, hit_normal, V_view, hit_albedo, roughness, metallic,
-                                                                light_emission(sc, center_r.light_idx), ld3(center_r.light_pos), ld3(center_r.light_normal));
-                            const float cr = rnd(rng);
-                            merge_reservoirs(spatial_r, center_r, maxc(fc), cr);
-                        }
-                        const float current_depth = len3(hitPos - origin);
-                        for (int s = 0; s < 5; s++) {  // SPATIAL_SAMPLES = 5, SPATIAL_RADIUS = 30
-                            const float angle = rnd(rng) * 2.0f * 3.14159f;
-                            const float radius = sqrtf(rnd(rng)) * 30.0f;
-                            float sa, ca; sincos_pinned(angle, sa, ca);
-                            const int ncx = ipx + (int)(ca * radius), ncy = ipy + (int)(sa * radius);
-                            if (ncx < 0 || ncy < 0 || ncx >= (int)W || ncy >= (int)H) continue;
-                            const uint32_t pi_n = (uint32_t)ncy * W + (uint32_t)ncx;
-                            const f3 neighbor_normal = load_normal(a, pi_n);
-                            const float neighbor_depth = load_depth(a, pi_n);
-                            if (dot3(hit_normal, neighbor_normal) < 0.9f) continue;
-                            if (fabsf(current_depth - neighbor_depth) > 0.1f * current_depth) continue;
-                            SrReservoir nr = load48(reservoir_cur + pi_n);
-                            nr.W = fminf(nr.W, 20.0f);
-                            nr.M = fminf(nr.M, 10.0f);
-                            if (nr.W > 0.0f && nr.light_idx < num_lights) {
-                                nr.light_idx = nr.light_idx < num_lights - 1 ? nr.light_idx : num_lights - 1;
-                                const f3 fn = eval_unshadowed_light(hitPos, hit_normal, V_view, hit_albedo, roughness, metallic,
-                                                                    light_emission(sc, nr.light_idx), ld3(nr.light_pos), ld3(nr.light_normal));
-                                const float nrnd = rnd(rng);
-                                merge_reservoirs(spatial_r, nr, maxc(fn), nrnd);
-                            }
-                        }
-                        if (spatial_r.w_sum > 0.0f) {
-                            const f3 f_y_winner = eval_unshadowed_light(hitPos, hit_normal, V_view, hit_albedo, roughness, metallic,
-                                                                        light_emission(sc, spatial_r.light_idx), ld3(spatial_r.light_pos), ld3(spatial_r.light_normal));
-                            spatial_r.W = spatial_r.w_sum / fmaxf(spatial_r.M * maxc(f_y_winner), 1e-3f);
-                            spatial_r.W = fminf(spatial_r.W, 50.0f);
-                            f3 shadow_dir = ld3(spatial_r.light_pos) - hitPos;
-                            const float shadow_dist = fmaxf(len3(shadow_dir), 0.0001f);
-                            shadow_dir = shadow_dir / shadow_dist;
-                            if (dot3(hit_normal, shadow_dir) > 0.0f) {
-                                prd.dist = trace_shadow<V>(cx, hitPos, shadow_dir, shadow_dist);
-                                if (prd.dist < 0.0f) radiance = radiance + f_y_winner * throughput * spatial_r.W;
-                                prev_did_nee = true;
-                            }
-                        }
-                        // ReSTIR GI spatial reuse
-                        SrReservoirGI combined = load48(reservoir_gi_cur + pix);
-                        const float gi_current_depth = len3(hitPos - origin);
-                        for (int s = 0; s < 3; s++) {  // GI_SPATIAL_SAMPLES = 3, GI_SPATIAL_RADIUS = 20
-                            const float gi_angle = rnd(rng) * 2.0f * 3.14159f;
-                            const float gi_radius = sqrtf(rnd(rng)) * 20.0f;
-                            float sa, ca; sincos_pinned(gi_angle, sa, ca);
-                            const int ncx = ipx + (int)(ca * gi_radius), ncy = ipy + (int)(sa * gi_radius);
-                            if (ncx == ipx && ncy == ipy) continue;
-                            if (ncx < 0 || ncy < 0 || ncx >= (int)W || ncy >= (int)H) continue;
-                            const uint32_t pi_nn = (uint32_t)ncy * W + (uint32_t)ncx;
-                            const f3 neighbor_normal = load_normal(a, pi_nn);
-                            const float neighbor_depth = load_depth(a, pi_nn);
-                            if (dot3(hit_normal, neighbor_normal) < 0.9f) continue;
-                            if (fabsf(gi_current_depth - neighbor_depth) > 0.1f * gi_current_depth) continue;
-                            SrReservoirGI nr = load48(reservoir_gi_cur + pi_nn);
-                            if (nr.W <= 0.0f) continue;
-                            nr.W = fminf(nr.W, 10.0f);
-                            nr.M = fminf(nr.M, 10.0f);
-                            f3 n_origin, n_dir; f2 n_uv;
-                            primary_ray(a.mats, (uint32_t)ncx, (uint32_t)ncy, W, H, n_origin, n_dir, n_uv);
-                            const f3 neighbor_x1 = origin + n_dir * neighbor_depth;
-                            const f3 nsp = ld3(nr.sample_pos);
-                            const f3 w_new = nsp - hitPos;
-                            const f3 w_old = nsp - neighbor_x1;
-                            const float d_new = fmaxf(len3(w_new), 1e-4f);
-                            const float d_old = fmaxf(len3(w_old), 1e-4f);
-                            const f3 n_x2 = unpack_normal(nr.sample_normal_packed);
-                            const float cos_new = fmaxf(dot3(n_x2, (-w_new) / d_new), 0.0f);
-                            const float cos_old = fmaxf(dot3(n_x2, (-w_old) / d_old), 0.0f);
-                            if (cos_new <= 0.0f || cos_old <= 0.0f) continue;
-                            float jacobian = (cos_new * d_old * d_old) / fmaxf(cos_old * d_new * d_new, 1e-4f);
-                            jacobian = clampf(jacobian, 0.0f, 10.0f);
-                            const f3 gi_spatial_dir = w_new / d_new;
-                            if (dot3(hit_normal, gi_spatial_dir) <= 0.0f) continue;
-                            prd.dist = trace_shadow<V>(cx, hitPos, gi_spatial_dir, d_new);
-                            if (prd.dist >= 0.0f) continue;
-                            const float p_hat_neighbor = gi_target_pdf(hitPos, hit_normal, hit_albedo, metallic, nsp, ld3(nr.sample_radiance));
-                            const float gr = rnd(rng);
-                            merge_reservoirs_gi(combined, nr, p_hat_neighbor, jacobian, gr);
-                        }
-                        const float p_hat_final = gi_target_pdf(hitPos, hit_normal, hit_albedo, metallic, ld3(combined.sample_pos), ld3(combined.sample_radiance));
-                        combined.W = (p_hat_final > 1e-3f) ? (combined.w_sum / fmaxf(combined.M, 1.0f) / p_hat_final) : 0.0f;
-                        combined.W = fminf(combined.W, 20.0f);
-                        if (combined.W > 0.0f) {
-                            f3 gi_x2_dir = ld3(combined.sample_pos) - hitPos;
-                            const float gi_x2_dist = fmaxf(len3(gi_x2_dir), 0.0001f);
-                            gi_x2_dir = gi_x2_dir / gi_x2_dist;
-                            const float gi_NdotL = fmaxf(dot3(hit_normal, gi_x2_dir), 0.0f);
-                            if (gi_NdotL > 0.0f) {
-                                prd.dist = trace_shadow<V>(cx, hitPos, gi_x2_dir, gi_x2_dist);
-                                if (prd.dist < 0.0f) {
-                                    const f3 gi_f_diffuse = hit_albedo * (1.0f - metallic) / 3.14159f;
-                                    radiance = radiance + ld3(combined.sample_radiance) * gi_f_diffuse * gi_NdotL * combined.W * throughput;
-                                }
-                            }
-                        }
-                        break;
-                    } else if (restir_evaluated && roughness > 0.2f) {
-                        uint32_t light_idx = (uint32_t)(rnd(rng) * (float)num_lights);
-                        if (light_idx > num_lights - 1) light_idx = num_lights - 1;
-                        const LightTri lt = fetch_light(sc, light_idx);
-                        const float light_area = lt.area;
-                        const float r1_nee = rnd(rng);
-                        const float r2_nee = rnd(rng);
-                        const float sqr1 = sqrtf(r1_nee);
-                        const float u = 1.0f - sqr1;
-                        const float v = r2_nee * sqr1;
-                        const float w = 1.0f - u - v;
-                        const f3 light_pos = lt.wv0 * u + lt.wv1 * v + lt.wv2 * w;
-                        const f3 light_normal = lt.normal;
-                        f3 shadow_ray_dir = light_pos - hitPos;
-                        const float light_dist = len3(shadow_ray_dir);
-                        shadow_ray_dir = shadow_ray_dir / light_dist;
-                        const float cos_theta_light = fmaxf(dot3(light_normal, -shadow_ray_dir), 0.0f);
-                        const float cos_theta_surface = fmaxf(dot3(hit_normal, shadow_ray_dir), 0.0f);
-                        if (cos_theta_light > 0.0f && cos_theta_surface > 0.0f) {
-                            prd.dist = trace_shadow<V>(cx, hitPos, shadow_ray_dir, light_dist);
-                            if (prd.dist < 0.0f) {
-                                const float solid_angle_pdf = (light_dist * light_dist) / fmaxf(cos_theta_light * light_area * (float)num_lights, 1e-4f);
-                                const f3 nee_contrib = (lt.emission * hit_albedo * throughput * cos_theta_surface) / (solid_angle_pdf * 3.14159f);
-                                radiance = radiance + vmin(nee_contrib, splat(5.0f));
-                            }
-                            prev_did_nee = true;
-                        }
-                    }
-                }
-
-                // BRDF bounce
-                const f3 N = hit_normal;
-                const f3 F0 = lerp3(splat(0.04f), hit_albedo, metallic);
-                const float cos_theta = fmaxf(dot3(N, V_view), 0.0f);
-                const f3 F = F0 + (1.0f - F0) * pow5f(clampf(1.0f - cos_theta, 0.0f, 1.0f));
-                const float p_specular = clampf(maxc(F), 0.05f, 1.0f);
-                float r1, r2;
-                if (bounce == 0) {
-                    r1 = fracf(bn_1 + (float)(a.frame_count % 1024u) * 0.75487766f);
-                    r2 = fracf(bn_2 + (float)(a.frame_count % 1024u) * 0.56984029f);
-                } else {
-                    r1 = rnd(rng);
-                    r2 = rnd(rng);
-                }
-                if (rnd(rng) < p_specular) {
-                    const f3 Hh = sample_ggx_vndf(N, V_view, roughness, r1, r2);
-                    rayDir = reflect3(-V_view, Hh);
-                    if (dot3(N, rayDir) <= 0.0f) {
-                        rayDir = get_random_bounce(N, r1, r2);
-                        throughput = throughput * (hit_albedo * (1.0f - metallic) * (1.0f - F) / (1.0f - p_specular));
-                    } else {
-                        const float NdotL_b = fmaxf(dot3(N, rayDir), 0.001f);
-                        const float alpha_b = roughness * roughness;
-                        const float G1_L = smith_g1_ggx(NdotL_b, alpha_b);
-                        throughput = throughput * ((F * G1_L) / p_specular);
-                    }
-                } else {
-                    rayDir = get_random_bounce(N, r1, r2);
-                    throughput = throughput * (hit_albedo * (1.0f - metallic) * (1.0f - F) / (1.0f - p_specular));
-                }
-                const float p = maxc(throughput);
-                if (p < 0.001f) break;
-                if (bounce > 2) {
-                    if (rnd(rng) > p) break;
-                    throughput = throughput / p;
-                }
-                rayOrigin = hitPos + hit_normal * 0.001f;
-            }
-            total_radiance = total_radiance + radiance;
-            total_radiance = vmin(total_radiance, splat(10.0f));
-        }
-        const f3 color = total_radiance / 1.0f;  // / float(SAMPLES)
-        float4 o;
-        o.x = color.x; o.y = color.y; o.z = color.z; o.w = 1.0f;
-        reinterpret_cast<float4*>(a.raw_color)[pix] = o;
-    }
-    record_tile_cost(a, cost_slot, t_start);
-    if (!(a.cfg.flags & SR_TRACE_FLAG_UNCOUNTED)) {
-        const bool counted = a.cfg.count_rows == 0u || (py - a.cfg.count_y0) < a.cfg.count_rows;   // per lane: its pixel's row
-        flush_counter(sc.counters + 0, counted ? cx.n_closest : 0u);
-        flush_counter(sc.counters + 1, counted ? cx.n_any : 0u);
-        if (V & 1) { flush_counter(sc.counters + 2, counted ? cx.st.boxes : 0u); flush_counter(sc.counters + 3, counted ? cx.st.tris : 0u); }
-    }
-}
-#endif
 
 }  // namespace srd
 
@@ -1263,9 +954,9 @@ int srk_launch_shade(const DevScene& sc, const SrHit* hits, uint32_t n, SrRayPay
 // (closest_hit's texture half compiled in). Untextured scenes run the variant without it.
 int srk_launch_pass(const PassArgs& args_in, int which, int stats, int textured, int stack_entries, hipStream_t stream) {
     PassArgs args = args_in;
-    args.tiles_x = (args.width + kPassTile - 1) / kPassTile;
+    args.tiles_x = (args.x1 - args.x0 + kPassTile - 1) / kPassTile;
     args.tiles_y = (args.y1 - args.y0 + kPassTile - 1) / kPassTile;
-    args.order_cap = srk_pass_order_cap(args.width, args.y1 - args.y0);   // list length per XCD = blocks per XCD
+    args.order_cap = srk_pass_order_cap(args.x1 - args.x0, args.y1 - args.y0);   // list length per XCD = blocks per XCD
     const uint32_t n_tiles = args.tiles_x * args.tiles_y;
     if (n_tiles == 0) return 0;
     dim3 grid(args.order_cap * 8), block(kPassBlock);

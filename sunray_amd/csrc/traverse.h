@@ -24,17 +24,11 @@
 
 namespace srd {
 
-#ifdef SR_STACK_BUDGET
-constexpr int kStackMax = SR_STACK_BUDGET;   // experiment hook (wider trees need a deeper stack)
-#else
-constexpr int kStackMax = 31;         // stack entries per lane the builders shape a tree for (= kMaxBinaryDepth); with the
-#endif                                // spare level of the branch-free push that is 32 LDS levels (8 KB per wave).
-                                      // Launches size the dynamic LDS stack to what the scene's tree actually needs.
+constexpr int kStackMax = 31;        // stack entries per lane the builders shape a tree for (= kMaxBinaryDepth); with the spare
+                                     // level of the branch-free push that is 32 LDS levels (8 KB per wave). Launches size the
+                                     // dynamic LDS stack to what the scene's tree actually needs.
 constexpr int kMaxBinaryDepth = 31;  // depth bound of the binary tree the 4-wide tree is collapsed from
 constexpr int kSentinel = 0x7fffffff;
-#ifndef SR_SPECULATIVE
-#define SR_SPECULATIVE 1   // speculative traversal (0: plain while-while, kept for A/B runs)
-#endif
 
 struct DevInstance {   // 96 B: (float3x3)WorldToObject3x4 in w2o[0..8], (float3x3)ObjectToWorld3x4 in o2w[0..8], row-major
     float w2o[12];
@@ -163,218 +157,16 @@ SRD bool child_hit(const NodePlanes& p, float t_lo, float t_hi, float& tnear) {
     return t0 <= fminf(far, t_hi);
 }
 
-// LDS stack: element k of this lane's column lives at stack_base[k * stride]. The builder bounds the
-// number of entries a traversal of the tree can need (BvhResult::max_stack <= kStackMax): no overflow path.
-#define SR_PUSH(v) do { stack_base[sp * stride] = (v); sp++; } while (0)
-#define SR_POP() (sp == 0 ? kSentinel : stack_base[(--sp) * stride])
-
+// LDS stack: element k of this lane's column lives at stack_base[k * stride]. The builder bounds the number of entries
+// a traversal of the tree can need (BvhResult::max_stack <= kStackMax): no overflow path.
 SRD int pick(int4 c, uint32_t i) {   // two levels of selects (v_cndmask), no branches
     const int lo = (i & 1u) ? c.y : c.x;
     const int hi = (i & 1u) ? c.w : c.z;
     return (i & 2u) ? hi : lo;
 }
 
-SRD bool first_active_lane() {   // diagnostics only
-    const unsigned long long m = __ballot(1);
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u;
-}
-
-template <bool ANY, bool STATS>
-SRD bool traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, TravHit& hit, int* stack_base, int stride, TravStats& st) {
-    const float4* __restrict__ nodes = sc.nodes;
-    const float4* __restrict__ tris = sc.tris;
-    const RaySetup rs = ray_setup(o, d);
-    const uint32_t boxes_at_entry = STATS ? st.boxes : 0u;
-    // Near bound of the box test: one |tmin| BELOW tmin. Close to the origin the triangle test's t carries
-    // an absolute error far above 1e-5*tmin (cancellation in o - v0), so a relative slack is not enough.
-    const float t_lo = fminf(tmin, 0.0f) - fabsf(tmin);
-    // Box culling bounds are relaxed on both ends; only the triangle test applies the exact (tmin, tmax).
-    float cull = fmaf(fabsf(tmax), 1e-5f, tmax);
-    float best_t = tmax;
-    hit.t = -1.0f; hit.u = 0.0f; hit.v = 0.0f; hit.gid = 0xFFFFFFFFu; hit.slot = 0u;
-    int sp = 0;
-    int node = 0;  // the root is always inner node 0
-#if SR_SPECULATIVE
-    int leaf = 0;  // postponed leaf reference (leaf references are negative; 0 = none)
-#endif
-#if SR_DIAG_UTIL == 2   // tuning diagnostics (variants only): lanes that enter a query vs 64 per wave-call
-    if (STATS) { st.boxes += 1; if (first_active_lane()) st.tris += 64; }
-#endif
-    while (node != kSentinel) {
-#if SR_SPECULATIVE
-        bool searching = true;
-#endif
-#if SR_BVH_WIDTH == 8
-        while (node >= 0 && node != kSentinel) {   // while-while: an if-if loop (one node of either kind per iteration) measured 5 % slower
-            const float4* n = nodes + (size_t)node * (srl::kNodeDwords / 4);
-            const float4 h0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], qa = n[4], qb = n[5];
-            const int4 ca = make_int4(__float_as_int(qa.x), __float_as_int(qa.y), __float_as_int(qa.z), __float_as_int(qa.w));
-            const int4 cb = make_int4(__float_as_int(qb.x), __float_as_int(qb.y), __float_as_int(qb.z), __float_as_int(qb.w));
-            if (STATS) st.boxes += 8;
-            const uint32_t ex = __float_as_uint(h0.w);
-            // planes: LX(2 dwords) LY(2) | LZ(2) HX(2) | HY(2) HZ(2); dword 0 of a plane = children 0..3, dword 1 = children 4..7
-            const uint32_t LX0 = __float_as_uint(q1.x), LX1 = __float_as_uint(q1.y), LY0 = __float_as_uint(q1.z), LY1 = __float_as_uint(q1.w);
-            const uint32_t LZ0 = __float_as_uint(q2.x), LZ1 = __float_as_uint(q2.y), HX0 = __float_as_uint(q2.z), HX1 = __float_as_uint(q2.w);
-            const uint32_t HY0 = __float_as_uint(q3.x), HY1 = __float_as_uint(q3.y), HZ0 = __float_as_uint(q3.z), HZ1 = __float_as_uint(q3.w);
-            NodePlanes p, r;      // p: children 0..3, r: children 4..7
-            p.nx = rs.sx ? HX0 : LX0; p.fx = rs.sx ? LX0 : HX0; r.nx = rs.sx ? HX1 : LX1; r.fx = rs.sx ? LX1 : HX1;
-            p.ny = rs.sy ? HY0 : LY0; p.fy = rs.sy ? LY0 : HY0; r.ny = rs.sy ? HY1 : LY1; r.fy = rs.sy ? LY1 : HY1;
-            p.nz = rs.sz ? HZ0 : LZ0; p.fz = rs.sz ? LZ0 : HZ0; r.nz = rs.sz ? HZ1 : LZ1; r.fz = rs.sz ? LZ1 : HZ1;
-            p.ax = __uint_as_float((ex & 0xFFu) << 23) * rs.inv.x; p.ay = __uint_as_float(((ex >> 8) & 0xFFu) << 23) * rs.inv.y;
-            p.az = __uint_as_float(((ex >> 16) & 0xFFu) << 23) * rs.inv.z;
-            p.bx = (h0.x - rs.o.x) * rs.inv.x; p.by = (h0.y - rs.o.y) * rs.inv.y; p.bz = (h0.z - rs.o.z) * rs.inv.z;
-            r.ax = p.ax; r.ay = p.ay; r.az = p.az; r.bx = p.bx; r.by = p.by; r.bz = p.bz;
-            float n0, n1, n2, n3, n4, n5, n6, n7;
-            const bool b0 = child_hit<0>(p, t_lo, cull, n0), b1 = child_hit<1>(p, t_lo, cull, n1);
-            const bool b2 = child_hit<2>(p, t_lo, cull, n2), b3 = child_hit<3>(p, t_lo, cull, n3);
-            const bool b4 = child_hit<0>(r, t_lo, cull, n4), b5 = child_hit<1>(r, t_lo, cull, n5);
-            const bool b6 = child_hit<2>(r, t_lo, cull, n6), b7 = child_hit<3>(r, t_lo, cull, n7);
-            // nearest hit child first (any-hit: any hit child), the other hit children pushed unordered and branch-free;
-            // key = entry distance with the low 3 mantissa bits replaced by the child slot
-            uint32_t k0, k1, k2, k3, k4, k5, k6, k7;
-            if (ANY) {
-                k0 = b0 ? 0u : 0xFFFFFFFFu; k1 = b1 ? 1u : 0xFFFFFFFFu; k2 = b2 ? 2u : 0xFFFFFFFFu; k3 = b3 ? 3u : 0xFFFFFFFFu;
-                k4 = b4 ? 4u : 0xFFFFFFFFu; k5 = b5 ? 5u : 0xFFFFFFFFu; k6 = b6 ? 6u : 0xFFFFFFFFu; k7 = b7 ? 7u : 0xFFFFFFFFu;
-            } else {
-                k0 = b0 ? ((__float_as_uint(fmaxf(n0, 0.0f)) & ~7u) | 0u) : 0xFFFFFFFFu;
-                k1 = b1 ? ((__float_as_uint(fmaxf(n1, 0.0f)) & ~7u) | 1u) : 0xFFFFFFFFu;
-                k2 = b2 ? ((__float_as_uint(fmaxf(n2, 0.0f)) & ~7u) | 2u) : 0xFFFFFFFFu;
-                k3 = b3 ? ((__float_as_uint(fmaxf(n3, 0.0f)) & ~7u) | 3u) : 0xFFFFFFFFu;
-                k4 = b4 ? ((__float_as_uint(fmaxf(n4, 0.0f)) & ~7u) | 4u) : 0xFFFFFFFFu;
-                k5 = b5 ? ((__float_as_uint(fmaxf(n5, 0.0f)) & ~7u) | 5u) : 0xFFFFFFFFu;
-                k6 = b6 ? ((__float_as_uint(fmaxf(n6, 0.0f)) & ~7u) | 6u) : 0xFFFFFFFFu;
-                k7 = b7 ? ((__float_as_uint(fmaxf(n7, 0.0f)) & ~7u) | 7u) : 0xFFFFFFFFu;
-            }
-            const uint32_t kmin = min(min(min(k0, k1), min(k2, k3)), min(min(k4, k5), min(k6, k7)));
-            const uint32_t slot = kmin & 7u;
-            stack_base[sp * stride] = ca.x; sp += (b0 && k0 != kmin) ? 1 : 0;
-            stack_base[sp * stride] = ca.y; sp += (b1 && k1 != kmin) ? 1 : 0;
-            stack_base[sp * stride] = ca.z; sp += (b2 && k2 != kmin) ? 1 : 0;
-            stack_base[sp * stride] = ca.w; sp += (b3 && k3 != kmin) ? 1 : 0;
-            stack_base[sp * stride] = cb.x; sp += (b4 && k4 != kmin) ? 1 : 0;
-            stack_base[sp * stride] = cb.y; sp += (b5 && k5 != kmin) ? 1 : 0;
-            stack_base[sp * stride] = cb.z; sp += (b6 && k6 != kmin) ? 1 : 0;
-            stack_base[sp * stride] = cb.w; sp += (b7 && k7 != kmin) ? 1 : 0;
-            const int lo4 = pick(ca, slot), hi4 = pick(cb, slot);
-            node = (kmin != 0xFFFFFFFFu) ? ((slot & 4u) ? hi4 : lo4) : SR_POP();
-#if SR_SPECULATIVE
-            if (node < 0 && leaf == 0) { searching = false; leaf = node; node = SR_POP(); }
-            if (__ballot(searching) == 0ull) break;
-#endif
-        }
-#else
-        while (node >= 0 && node != kSentinel) {   // while-while: an if-if loop (one node of either kind per iteration) measured 5 % slower
-            const float4* n = nodes + (size_t)node * 4;
-            const float4 h0 = n[0], q1 = n[1], q2 = n[2], qc = n[3];
-            const int4 child = make_int4(__float_as_int(qc.x), __float_as_int(qc.y), __float_as_int(qc.z), __float_as_int(qc.w));
-#if SR_DIAG_UTIL == 1       // tuning diagnostics: active lanes per node step vs 64 per wave-step (first active lane counts the wave)
-            if (STATS) { st.boxes += 1; if (first_active_lane()) st.tris += 64; }
-#elif SR_DIAG_UTIL == 3     // same for the triangle loop (below)
-#elif SR_DIAG_UTIL == 2
-#else
-            if (STATS) st.boxes += 4;
-#endif
-            const uint32_t ex = __float_as_uint(h0.w);
-            const uint32_t LX = __float_as_uint(q1.x), LY = __float_as_uint(q1.y), LZ = __float_as_uint(q1.z);
-            const uint32_t HX = __float_as_uint(q1.w), HY = __float_as_uint(q2.x), HZ = __float_as_uint(q2.y);
-            NodePlanes p;
-            p.nx = rs.sx ? HX : LX; p.fx = rs.sx ? LX : HX;
-            p.ny = rs.sy ? HY : LY; p.fy = rs.sy ? LY : HY;
-            p.nz = rs.sz ? HZ : LZ; p.fz = rs.sz ? LZ : HZ;
-            p.ax = __uint_as_float((ex & 0xFFu) << 23) * rs.inv.x; p.ay = __uint_as_float(((ex >> 8) & 0xFFu) << 23) * rs.inv.y;
-            p.az = __uint_as_float(((ex >> 16) & 0xFFu) << 23) * rs.inv.z;
-            p.bx = (h0.x - rs.o.x) * rs.inv.x; p.by = (h0.y - rs.o.y) * rs.inv.y; p.bz = (h0.z - rs.o.z) * rs.inv.z;
-            float n0, n1, n2, n3;
-            const bool b0 = child_hit<0>(p, t_lo, cull, n0);
-            const bool b1 = child_hit<1>(p, t_lo, cull, n1);
-            const bool b2 = child_hit<2>(p, t_lo, cull, n2);
-            const bool b3 = child_hit<3>(p, t_lo, cull, n3);
-            // Continue with the nearest hit child (an existence query: with any hit child), push the other hit children.
-            // Pushes are branch-free: every child reference is stored at the current stack top and the top only
-            // advances for a child that is hit and not the one continued with (the launchers allocate one spare stack
-            // level for the store that does not advance). On average 1.2 children of a node are hit, so ordering the
-            // pushed ones as well (a full 4-key sorting network + per-key selects) costs more than it saves.
-            uint32_t k0, k1, k2, k3;
-            if (ANY) {
-                k0 = b0 ? 0u : 0xFFFFFFFFu; k1 = b1 ? 1u : 0xFFFFFFFFu; k2 = b2 ? 2u : 0xFFFFFFFFu; k3 = b3 ? 3u : 0xFFFFFFFFu;
-            } else {
-                // key = entry distance (clamped to >= 0, low 2 mantissa bits replaced by the child slot): positive floats
-                // order like unsigned integers
-                k0 = b0 ? ((__float_as_uint(fmaxf(n0, 0.0f)) & ~3u) | 0u) : 0xFFFFFFFFu;
-                k1 = b1 ? ((__float_as_uint(fmaxf(n1, 0.0f)) & ~3u) | 1u) : 0xFFFFFFFFu;
-                k2 = b2 ? ((__float_as_uint(fmaxf(n2, 0.0f)) & ~3u) | 2u) : 0xFFFFFFFFu;
-                k3 = b3 ? ((__float_as_uint(fmaxf(n3, 0.0f)) & ~3u) | 3u) : 0xFFFFFFFFu;
-            }
-            const uint32_t kmin = min(min(k0, k1), min(k2, k3));
-            const uint32_t slot = kmin & 3u;
-            stack_base[sp * stride] = child.x; sp += (b0 && k0 != kmin) ? 1 : 0;
-            stack_base[sp * stride] = child.y; sp += (b1 && k1 != kmin) ? 1 : 0;
-            stack_base[sp * stride] = child.z; sp += (b2 && k2 != kmin) ? 1 : 0;
-            stack_base[sp * stride] = child.w; sp += (b3 && k3 != kmin) ? 1 : 0;
-            node = (kmin != 0xFFFFFFFFu) ? pick(child, slot) : SR_POP();
-#if SR_SPECULATIVE
-            // speculative traversal (Aila & Laine 2009): a lane that has reached its first leaf postpones it and keeps
-            // walking until every lane of the wave holds a leaf, so the triangle phase runs with fuller waves
-            if (node < 0 && leaf == 0) { searching = false; leaf = node; node = SR_POP(); }
-            if (__ballot(searching) == 0ull) break;
-#endif
-        }
-#endif
-#if SR_SPECULATIVE
-        if (leaf == 0) break;   // nothing postponed: the walk ended on the sentinel
-        // Triangle phase, one triangle per lane and iteration: the postponed leaf first, then the leaf the walk stopped at
-        // (if any) and leaves popped after it. A leaf reference is ~(first << 3 | count): taking one triangle off its
-        // front is integer arithmetic, so lanes with short leaves move on to their next leaf instead of idling.
-        while (leaf != 0) {
-            const uint32_t lv = ~(uint32_t)leaf;
-            const uint32_t slot = lv >> 3, cnt = lv & 7u;
-            leaf = cnt > 1u ? (int)~(((slot + 1u) << 3) | (cnt - 1u)) : 0;
-            if (leaf == 0 && node < 0) { leaf = node; node = SR_POP(); }
-            if (cnt == 0u) continue;   // empty leaf (a builder's filler child; its box cannot be hit, kept for robustness)
-#else
-        if (node == kSentinel) break;
-        const uint32_t lv = ~(uint32_t)node;
-        const uint32_t first = lv >> 3, cnt = lv & 7u;
-        for (uint32_t slot = first; slot < first + cnt; slot++) {
-#endif
-            const float4 t0 = tris[(size_t)slot * 3 + 0];
-            const float4 t1 = tris[(size_t)slot * 3 + 1];
-            const float4 t2 = tris[(size_t)slot * 3 + 2];
-            float t, u, v;
-#if SR_DIAG_UTIL == 3
-            if (STATS) { st.boxes += 1; if (first_active_lane()) st.tris += 64; }
-#elif !SR_DIAG_UTIL
-            if (STATS) st.tris += 1;
-#endif
-            if (intersect_tri(o, d, mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), tmin, tmax, t, u, v)) {
-                if (ANY) return true;
-                const uint32_t gid = __float_as_uint(t2.y);
-                if (t < best_t || (t == best_t && gid < hit.gid)) {
-                    best_t = t;
-                    hit.t = t; hit.u = u; hit.v = v;
-                    hit.gid = gid; hit.slot = slot;
-                    cull = fmaf(fabsf(t), 1e-5f, t);
-                }
-            }
-        }
-#if !SR_SPECULATIVE
-        node = SR_POP();
-#endif
-    }
-    if (STATS) {   // diagnostics: remember the most expensive ray of the launch
-        const uint32_t steps = st.boxes - boxes_at_entry;
-        uint32_t* dbg = reinterpret_cast<uint32_t*>(sc.counters) + 16;
-        if (steps > 20000u && atomicMax(dbg, steps) < steps) {
-            float* r = reinterpret_cast<float*>(dbg + 8);
-            r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = tmin; r[4] = d.x; r[5] = d.y; r[6] = d.z; r[7] = tmax;
-            dbg[1] = ANY ? 1u : 0u;
-        }
-    }
-    return hit.gid != 0xFFFFFFFFu;
-}
-
 // ---------------------------------------------------------------------------------------------
-// Work-stealing traversal (4-wide trees). Rays of one wave differ a lot in length: measured on the bench frame, the
+// Traversal with work stealing inside the wave. Rays of one wave differ a lot in length: measured on the bench frame, the
 // lanes that enter a query together are busy for only half of the wave's node steps, the rest have finished and wait
 // for the longest ray. Here a lane that runs out of work takes the BOTTOM entry of a busy lane's stack (the stacks
 // live in LDS, one column per lane, so any lane of the wave can read them) together with that lane's ray, and walks
@@ -458,11 +250,7 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                 const float4* n = nodes + (size_t)node * 4;
                 const float4 h0 = n[0], q1 = n[1], q2 = n[2], qc = n[3];
                 const int4 child = make_int4(__float_as_int(qc.x), __float_as_int(qc.y), __float_as_int(qc.z), __float_as_int(qc.w));
-#if SR_DIAG_UTIL == 1
-                if (STATS) { st.boxes += 1; if (first_active_lane()) st.tris += 64; }
-#elif !SR_DIAG_UTIL
                 if (STATS) st.boxes += 4;
-#endif
                 const uint32_t ex = __float_as_uint(h0.w);
                 const uint32_t LX = __float_as_uint(q1.x), LY = __float_as_uint(q1.y), LZ = __float_as_uint(q1.z);
                 const uint32_t HX = __float_as_uint(q1.w), HY = __float_as_uint(q2.x), HZ = __float_as_uint(q2.y);
@@ -507,11 +295,7 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
             const float4 t1 = tris[(size_t)slot * 3 + 1];
             const float4 t2 = tris[(size_t)slot * 3 + 2];
             float t, u, v;
-#if SR_DIAG_UTIL == 3
-            if (STATS) { st.boxes += 1; if (first_active_lane()) st.tris += 64; }
-#elif !SR_DIAG_UTIL
             if (STATS) st.tris += 1;
-#endif
             if (intersect_tri(o, d, mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), tmin, tmax, t, u, v)) {
                 if (ANY) { keys[root] = 0ull; node = kSentinel; sp = sb; leaf = 0; break; }
                 const uint32_t gid = __float_as_uint(t2.y);

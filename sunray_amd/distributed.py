@@ -1,132 +1,200 @@
 """Tile-parallel rendering of one frame across the GPUs of a node.
 
-One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm). The scene is
-replicated; the screen is cut into `world` contiguous row strips. Pixels are keyed by their GLOBAL
-coordinates (RNG seed, camera ray), so a strip traced alone carries exactly the values it has in a
-single-GPU frame. The only data-path exchange is the gather of the fp32 radiance strips.
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm). The scene is replicated; the screen is
+cut into `world` contiguous strips — COLUMN strips by default: image cost varies mostly with the row (sky / horizon /
+foreground), so column strips hand every GPU the same mix of rows, exactly as the kernels cut the image into column bands
+across the XCDs of one GPU; row strips remain available (`axis="rows"`). Pixels are keyed by their GLOBAL coordinates
+(RNG seed, camera ray), so a strip traced alone carries exactly the values it has in a single-GPU frame. The data-path
+exchange is the gather of the fp32 radiance strips, one collective per frame.
 
-ReSTIR makes pixels depend on neighbours: the final pass reads reservoirs / normal / depth within a
-30-pixel radius (ray_gen_final.slang:160-188,228-247). Each rank therefore re-traces the RIS pass on
-a 30-row halo above and below its strip (recompute instead of exchange; those launches carry
-SR_TRACE_FLAG_UNCOUNTED so counted rays stay those of the single-GPU frame). Temporal reuse reads the
-previous frame's reservoir at the reprojected pixel (ray_gen_ris.slang:234-266): with a static camera
-that is the pixel itself, so strip + halo is self-contained and N-GPU output is bit-identical to
-1-GPU; under camera motion the outermost halo rows may read history this rank never computed.
+ReSTIR makes pixels depend on neighbours:
+  * spatial reuse — the final pass reads reservoirs / normal / depth within a 30-pixel radius
+    (ray_gen_final.slang:160-188,228-247). Each rank therefore traces the RIS pass over its strip plus a 30-pixel halo
+    on either side (recompute instead of exchange: 2*30/240 = 25 % extra RIS columns at 1080p on 8 GPUs, 12.5 % at 4K;
+    with row strips 44 % / 22 %); only the strip's own pixels count their rays (SrTraceConfig.count_*).
+  * temporal reuse — the RIS pass reads the PREVIOUS frame's reservoirs at the reprojected pixel
+    (ray_gen_ris.slang:234-266,408-431). With a static camera that is the pixel itself and strip + halo is
+    self-contained. Under camera motion the reprojected pixel of a halo pixel can lie up to `motion_halo` pixels further
+    out, in pixels this rank never traced: `exchange_history` fetches those reservoir bands from the ranks that own them
+    (point-to-point over RCCL / gloo) after every RIS pass, so the history a rank reads is always the single-GPU one and
+    N-GPU output stays bit-identical to 1-GPU for a moving camera as well (tests/test_distributed_gloo.py).
 """
 import copy
 
 SPATIAL_HALO = 30  # SPATIAL_RADIUS (ray_gen_final.slang:161) >= GI_SPATIAL_RADIUS (:229)
 
 
-def strip_rows(height, world, rank):
-    """Rows [y0, y0+h) of rank's strip; equal ceil(height/world) rows, the last strips may be short/empty."""
-    per = (height + world - 1) // world
-    y0 = min(rank * per, height)
-    return y0, min(per, height - y0)
+class Partition:
+    """`world` contiguous strips of a width x height image along one axis. `bounds` (world + 1 increasing cut positions,
+    e.g. from balanced_bounds) replaces the equal split; it must stay the same for a whole frame sequence: a rank owns
+    the temporal history of exactly its strip + halo."""
+
+    def __init__(self, width, height, world, axis="cols", bounds=None):
+        if axis not in ("cols", "rows"):
+            raise ValueError("axis must be 'cols' or 'rows'")
+        self.width, self.height, self.world, self.axis = width, height, world, axis
+        self.length = width if axis == "cols" else height
+        if bounds is None:
+            per = (self.length + world - 1) // world
+            bounds = [min(r * per, self.length) for r in range(world)] + [self.length]
+        bounds = [int(v) for v in bounds]
+        if len(bounds) != world + 1 or bounds[0] != 0 or bounds[-1] != self.length or any(b > a for b, a in zip(bounds, bounds[1:])):
+            raise ValueError("bounds must be %d increasing cuts from 0 to %d" % (world + 1, self.length))
+        self.bounds = bounds
+
+    def span(self, rank):
+        """(start, size) of rank's strip along the axis."""
+        return self.bounds[rank], self.bounds[rank + 1] - self.bounds[rank]
+
+    def sizes(self):
+        return [self.bounds[r + 1] - self.bounds[r] for r in range(self.world)]
+
+    def tile(self, a0, n):
+        """The (y0, h, x0, w) launch rectangle of positions [a0, a0 + n) along the axis, full extent across it."""
+        return (0, self.height, a0, n) if self.axis == "cols" else (a0, n, 0, self.width)
+
+    def grown(self, rank, grow):
+        """(start, size) of rank's strip grown by `grow` on both sides, clipped to the image."""
+        a0, n = self.span(rank)
+        lo, hi = max(0, a0 - grow), min(self.length, a0 + n + grow)
+        return lo, hi - lo
+
+    def view(self, flat, channels=None):
+        """[H, W(, C)] view of a per-pixel buffer (torch tensor or numpy array of H*W rows)."""
+        return flat.reshape(self.height, self.width, -1) if channels is None else flat.reshape(self.height, self.width, channels)
+
+    def cut(self, img, a0, n):
+        """Slice [a0, a0 + n) along the axis of an [H, W, C] view."""
+        return img[:, a0:a0 + n] if self.axis == "cols" else img[a0:a0 + n]
 
 
-def balanced_bounds(row_cost, world, min_rows=8, max_share=2.5):
-    """Cuts the rows into `world` contiguous strips of (nearly) equal summed cost: returns world+1 increasing row
-    boundaries. Strips are cut one after the other, each taking 1/n of the cost that is left for the n ranks that are
-    left, with at least `min_rows` rows and at most max_share * height / world rows (the gather pads every strip to the
-    tallest one, so a very tall cheap strip would inflate the collective). Deterministic: every rank that feeds the
-    same profile gets the same cut, so no communication is needed to agree on it."""
+def balanced_bounds(cost, world, min_size=8, max_share=2.5):
+    """Cuts positions 0 .. len(cost) into `world` contiguous strips of (nearly) equal summed cost: returns world + 1
+    increasing cut positions. Strips are cut one after the other, each taking 1/n of the cost that is left for the n ranks
+    that are left, with at least `min_size` positions and at most max_share * length / world (the gather pads every strip
+    to the largest one, so a very large cheap strip would inflate the collective). Deterministic: every rank that feeds
+    the same profile gets the same cut."""
     import numpy as np
-    cost = np.maximum(np.asarray(row_cost, dtype=np.float64), 0.0) + 1e-12
-    height = len(cost)
-    min_rows = max(1, min(min_rows, height // max(world, 1)))
-    max_rows = max(int(np.ceil(max_share * height / max(world, 1))), min_rows)
+    cost = np.maximum(np.asarray(cost, dtype=np.float64), 0.0) + 1e-12
+    length = len(cost)
+    min_size = max(1, min(min_size, length // max(world, 1)))
+    max_size = max(int(np.ceil(max_share * length / max(world, 1))), min_size)
     cum = np.concatenate([[0.0], np.cumsum(cost)])
     bounds = [0]
     for k in range(world - 1):
         y, n = bounds[-1], world - k
         target = cum[y] + (cum[-1] - cum[y]) / n
         cut = int(np.searchsorted(cum, target, side="left"))
-        cut = min(max(cut, y + min_rows), y + max_rows)          # this strip: [min_rows, max_rows] rows
-        cut = max(cut, height - (n - 1) * max_rows)              # the ranks that are left can still cover the rest ...
-        cut = min(cut, height - (n - 1) * min_rows)              # ... and each gets its minimum
+        cut = min(max(cut, y + min_size), y + max_size)          # this strip: [min_size, max_size]
+        cut = max(cut, length - (n - 1) * max_size)              # the ranks that are left can still cover the rest ...
+        cut = min(cut, length - (n - 1) * min_size)              # ... and each gets its minimum
         bounds.append(max(cut, y))
-    bounds.append(height)
+    bounds.append(length)
     return [int(v) for v in bounds]
 
 
-def refine_bounds(row_cost, bounds, periods, damping=0.7, min_rows=32, max_share=2.5):
-    """One step of the feedback balancer: `periods[r]` is the measured step time of rank r with the cut `bounds`. A rank's
-    share of a frame is about one round of waves, so its time is not proportional to the cycle sum of its rows (the strip
-    that holds the horizon rows is bound by its slowest waves): the cost model is corrected where it was wrong — the rows
-    of rank r are re-weighted by (period_r / mean period) ** damping — and the rows are cut again. Returns
-    (new row_cost, new bounds). Deterministic; the caller keeps the cut with the smallest measured maximum."""
+def axis_cost_from_tiles(tile_costs, tiles_x, axis, length, tile=8):
+    """Per-pixel-column (or per-pixel-row) cost from the per-tile cycle counts the library records for its own tile
+    schedule (sr_scene_read_tile_costs, row-major ty * tiles_x + tx): what balanced_bounds cuts."""
     import numpy as np
-    cost = np.maximum(np.asarray(row_cost, dtype=np.float64), 0.0).copy()
-    world = len(bounds) - 1
-    p = np.maximum(np.asarray(periods, dtype=np.float64), 1e-9)
-    mean = float(p.mean())
-    for r in range(world):
-        cost[bounds[r]:bounds[r + 1]] *= (p[r] / mean) ** damping
-    return cost, balanced_bounds(cost, world, min_rows=min_rows, max_share=max_share)
+    t = np.asarray(tile_costs, dtype=np.float64).reshape(-1, tiles_x)
+    per_tile = t.sum(axis=0) if axis == "cols" else t.sum(axis=1)
+    return np.repeat(per_tile / float(tile), tile)[:length]
 
 
-def row_cost_from_depth(depth_u16, width, height, sky_weight=1.0, surface_weight=4.0):
-    """Per-row cost estimate from a G-buffer depth image (R16F bits): a sky pixel (depth +inf, ray_gen_ris.slang:168)
-    costs one primary ray per pass, a surface pixel the whole ReSTIR sequence (~6 rays, mostly incoherent)."""
-    import numpy as np
-    d = np.asarray(depth_u16).reshape(height, width)
-    sky = (d & 0x7FFF) >= 0x7C00
-    return sky_weight * sky.sum(axis=1) + surface_weight * (~sky).sum(axis=1)
-
-
-def halo_bands(height, y0, h, halo=SPATIAL_HALO):
-    """Row bands outside [y0, y0+h) within `halo` rows of it, clipped to the image."""
-    bands = []
-    if h <= 0:
-        return bands
-    top0 = max(0, y0 - halo)
-    if top0 < y0:
-        bands.append((top0, y0 - top0))
-    bot1 = min(height, y0 + h + halo)
-    if bot1 > y0 + h:
-        bands.append((y0 + h, bot1 - (y0 + h)))
-    return bands
-
-
-def _strip(height, world, rank, bounds):
-    return (bounds[rank], bounds[rank + 1] - bounds[rank]) if bounds is not None else strip_rows(height, world, rank)
-
-
-def trace_ris_strip(scene, frame, matrices, frame_count, cfg, world, rank, bounds=None):
-    """The RIS pass of this rank's strip. With world > 1 it is ONE launch over the strip and its halo rows: a rank's share
-    of a frame is small, so every extra launch adds a tail in which the GPU drains; only the strip's own rows count
-    their rays (SrTraceConfig.count_y0 / count_rows)."""
-    y0, h = _strip(frame.height, world, rank, bounds)
-    if h <= 0 or not cfg.enable_restir:
+def trace_ris_strip(scene, frame, matrices, frame_count, cfg, part, rank):
+    """The RIS pass of this rank's strip. With world > 1 it is ONE launch over the strip and its spatial halo: a rank's
+    share of a frame is small, so every extra launch adds a tail in which the GPU drains; only the strip's own pixels
+    count their rays."""
+    a0, n = part.span(rank)
+    if n <= 0 or not cfg.enable_restir:
         return
-    if world > 1:
-        bands = halo_bands(frame.height, y0, h)
-        r0 = min([y0] + [b[0] for b in bands])
-        r1 = max([y0 + h] + [b[0] + b[1] for b in bands])
+    if part.world > 1:
+        g0, gn = part.grown(rank, SPATIAL_HALO)
         rcfg = copy.copy(cfg)
-        rcfg.count_y0, rcfg.count_rows = y0, h
-        scene.trace_ris(frame, matrices, frame_count, rcfg, tile=(r0, r1 - r0))
+        if part.axis == "cols":
+            rcfg.count_x0, rcfg.count_cols = a0, n
+        else:
+            rcfg.count_y0, rcfg.count_rows = a0, n
+        scene.trace_ris(frame, matrices, frame_count, rcfg, tile=part.tile(g0, gn))
     else:
-        scene.trace_ris(frame, matrices, frame_count, cfg, tile=(y0, h))
+        scene.trace_ris(frame, matrices, frame_count, cfg, tile=part.tile(a0, n))
 
 
-def trace_final_strip(scene, frame, matrices, frame_count, cfg, world, rank, bounds=None):
-    y0, h = _strip(frame.height, world, rank, bounds)
-    if h > 0:
-        scene.trace_final(frame, matrices, frame_count, cfg, tile=(y0, h))
+def trace_final_strip(scene, frame, matrices, frame_count, cfg, part, rank):
+    a0, n = part.span(rank)
+    if n > 0:
+        scene.trace_final(frame, matrices, frame_count, cfg, tile=part.tile(a0, n))
 
 
-def render_strip(scene, frame, matrices, frame_count, cfg, world, rank, uncounted_flag=1, bounds=None):
+def history_exchange_plan(part, motion_halo):
+    """Who sends which reservoir band to whom after a RIS pass: rank r needs the pixels within SPATIAL_HALO + motion_halo
+    of its strip that lie outside strip + SPATIAL_HALO (those it traced itself); every such pixel is owned — and was
+    traced with exact history — by exactly one other rank. Returns a list of (src, dst, start, size) along the axis, in
+    a deterministic order every rank derives alike."""
+    plan = []
+    if motion_halo <= 0 or part.world <= 1:
+        return plan
+    for dst in range(part.world):
+        a0, n = part.span(dst)
+        if n <= 0:
+            continue
+        g0, gn = part.grown(dst, SPATIAL_HALO)
+        h0, hn = part.grown(dst, SPATIAL_HALO + motion_halo)
+        for lo, hi in ((h0, g0), (g0 + gn, h0 + hn)):         # the band before and the band after the traced region
+            for src in range(part.world):
+                if src == dst:
+                    continue
+                s0, sn = part.span(src)
+                x0, x1 = max(lo, s0), min(hi, s0 + sn)
+                if x1 > x0:
+                    plan.append((src, dst, x0, x1 - x0))
+    return plan
+
+
+def exchange_history(frame, frame_count, part, rank, motion_halo, as_tensor=None):
+    """After RIS(frame_count): fetch the DI and GI reservoirs of the bands `history_exchange_plan` assigns to this rank
+    from their owners, so that RIS(frame_count + 1) finds exact history wherever temporal reprojection can land
+    (|reprojected - pixel| <= motion_halo along the strip axis). Point-to-point (batch_isend_irecv); a no-op for a
+    static camera (motion_halo = 0). `as_tensor` turns a frame buffer into a torch tensor sharing its memory (numpy host
+    frames in the CPU tests); device frames hold torch tensors already."""
+    plan = [p for p in history_exchange_plan(part, motion_halo) if rank in (p[0], p[1])]
+    if not plan:
+        return
+    import torch
+    import torch.distributed as dist
+    cur = frame_count & 1
+    tt = as_tensor or (lambda b: b)
+    di = part.view(tt(frame.reservoirs[cur]), 12)
+    gi = part.view(tt(frame.reservoirs_gi[cur]), 12)
+    ops, landing = [], []
+    for src, dst, x0, n in plan:
+        if src == rank:
+            buf = torch.cat([part.cut(di, x0, n), part.cut(gi, x0, n)], dim=2).contiguous()
+            ops.append(dist.P2POp(dist.isend, buf, dst))
+        else:
+            shape = list(part.cut(di, x0, n).shape)
+            shape[2] = 24
+            buf = torch.empty(shape, dtype=di.dtype, device=di.device)
+            ops.append(dist.P2POp(dist.irecv, buf, src))
+            landing.append((buf, x0, n))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    for buf, x0, n in landing:
+        part.cut(di, x0, n).copy_(buf[:, :, :12])
+        part.cut(gi, x0, n).copy_(buf[:, :, 12:])
+
+
+def render_strip(scene, frame, matrices, frame_count, cfg, part, rank, motion_halo=0, as_tensor=None):
     """Traces this rank's part of one frame into the full-size buffers of `frame`.
 
     `scene` is a sunray_amd.runtime.Scene (GPU) — or, in the CPU tests, the oracle's scene: both offer
-    trace_ris / trace_final(frame, matrices, frame_count, cfg, tile=(y0, h)). `bounds` (balanced_bounds) replaces
-    the equal split; it must stay the same for the whole frame sequence (a rank keeps the temporal history of
-    exactly its rows + halo)."""
-    trace_ris_strip(scene, frame, matrices, frame_count, cfg, world, rank, bounds)
-    trace_final_strip(scene, frame, matrices, frame_count, cfg, world, rank, bounds)
-    return _strip(frame.height, world, rank, bounds)
+    trace_ris / trace_final(frame, matrices, frame_count, cfg, tile=(y0, h, x0, w))."""
+    trace_ris_strip(scene, frame, matrices, frame_count, cfg, part, rank)
+    if cfg.enable_restir:
+        exchange_history(frame, frame_count, part, rank, motion_halo, as_tensor)
+    trace_final_strip(scene, frame, matrices, frame_count, cfg, part, rank)
+    return part.span(rank)
 
 
 class FramePipeline:
@@ -147,63 +215,44 @@ class FramePipeline:
         self.ev_final = [torch.cuda.Event(), torch.cuda.Event()]
         self.torch = torch
 
-    def step(self, scene, matrices, frame_count, cfg, world, rank, bounds=None, after_final=None):
+    def step(self, scene, matrices, frame_count, cfg, part, rank, after_final=None, motion_halo=0):
         torch = self.torch
         k = frame_count & 1
         fr = self.frames[k]
         with torch.cuda.stream(self.s_ris):
             self.s_ris.wait_event(self.ev_final[k])          # final(f-2) has finished reading this G-buffer
-            trace_ris_strip(scene, fr, matrices, frame_count, cfg, world, rank, bounds)
+            trace_ris_strip(scene, fr, matrices, frame_count, cfg, part, rank)
+            if cfg.enable_restir:
+                exchange_history(fr, frame_count, part, rank, motion_halo)   # ordered on the RIS stream (RIS(f+1) reads it)
             self.ev_ris[k].record(self.s_ris)
         with torch.cuda.stream(self.s_final):
             self.s_final.wait_event(self.ev_ris[k])
-            trace_final_strip(scene, fr, matrices, frame_count, cfg, world, rank, bounds)
+            trace_final_strip(scene, fr, matrices, frame_count, cfg, part, rank)
             self.ev_final[k].record(self.s_final)
             if after_final is not None:
                 after_final(fr)                               # e.g. GatherPipeline.submit(fr.raw_color), on the final stream
         return fr
 
 
-def gather_strips(raw_color, width, height, world, rank, out=None, scratch=None):
-    """All-gathers the radiance strips into a full [H*W, 4] image on every rank (one collective).
-
-    raw_color: this rank's full-size [H*W, 4] float32 torch tensor, valid in its own strip."""
-    import torch
-    import torch.distributed as dist
-    per = (height + world - 1) // world
-    y0, h = strip_rows(height, world, rank)
-    if scratch is None:
-        scratch = torch.zeros(per * width, 4, dtype=raw_color.dtype, device=raw_color.device)
-    if h > 0:
-        scratch[: h * width].copy_(raw_color[y0 * width:(y0 + h) * width])
-    if out is None:
-        out = torch.empty(world * per * width, 4, dtype=raw_color.dtype, device=raw_color.device)
-    if world > 1:
-        dist.all_gather_into_tensor(out, scratch)
-    else:
-        out.copy_(scratch)
-    return out[: height * width]
-
-
 class GatherPipeline:
     """Asynchronous, double-buffered gather of the radiance strips: the collective of frame f runs on the collective
     library's own stream while the kernels of frame f+1 are already tracing (xGMI transfer hidden behind compute).
-    Strips may have different heights (balanced_bounds): every rank contributes a buffer padded to the tallest strip,
-    one `all_gather_into_tensor` per frame, and `image()` reassembles the rows.
+    Strips may differ in size (balanced_bounds): every rank contributes a buffer padded to the largest strip, one
+    `all_gather_into_tensor` per frame, and `image()` reassembles the image.
 
     submit(raw_color) copies this rank's strip out of the frame buffer (so the next frame may overwrite it) and starts
     the collective; wait(slot) makes the current stream wait for it. At most `depth` gathers are in flight."""
 
-    def __init__(self, width, height, world, rank, device, bounds=None, depth=2, dtype=None):
+    def __init__(self, part, rank, device, depth=2, dtype=None):
         import torch
         self.torch = torch
-        self.width, self.height, self.world, self.rank = width, height, world, rank
-        self.bounds = list(bounds) if bounds is not None else [min(r * ((height + world - 1) // world), height) for r in range(world)] + [height]
-        self.rows_max = max(self.bounds[r + 1] - self.bounds[r] for r in range(world))
+        self.part, self.rank = part, rank
+        self.size_max = max(part.sizes())
         dtype = dtype or torch.float32
-        n = self.rows_max * width
-        self.send = [torch.zeros(n, 4, dtype=dtype, device=device) for _ in range(depth)]
-        self.recv = [torch.empty(world * n, 4, dtype=dtype, device=device) for _ in range(depth)]
+        shape = (part.height, self.size_max, 4) if part.axis == "cols" else (self.size_max, part.width, 4)
+        self.send = [torch.zeros(*shape, dtype=dtype, device=device) for _ in range(depth)]
+        self.shape = shape
+        self.recv = [torch.empty(part.world * shape[0], shape[1], 4, dtype=dtype, device=device) for _ in range(depth)]   # concatenated along dim 0
         self.work = [None] * depth
         self.next = 0
         self.last = None
@@ -212,10 +261,10 @@ class GatherPipeline:
         import torch.distributed as dist
         k = self.next
         self.wait(k)                                   # the slot's previous gather must be done before its buffers are reused
-        y0, y1 = self.bounds[self.rank], self.bounds[self.rank + 1]
-        if y1 > y0:
-            self.send[k][: (y1 - y0) * self.width].copy_(raw_color[y0 * self.width:y1 * self.width])
-        if self.world > 1:
+        a0, n = self.part.span(self.rank)
+        if n > 0:
+            self.part.cut(self.send[k], 0, n).copy_(self.part.cut(self.part.view(raw_color, 4), a0, n))
+        if self.part.world > 1:
             fn = all_gather or (lambda out, inp: dist.all_gather_into_tensor(out, inp, async_op=True))
             self.work[k] = fn(self.recv[k], self.send[k])
         else:
@@ -232,9 +281,9 @@ class GatherPipeline:
                 self.work[i] = None
 
     def image(self, k=None):
-        """Full [H*W, 4] image of slot k (default: the last submitted), rows re-assembled from the padded strips."""
+        """Full [H*W, 4] image of slot k (default: the last submitted), re-assembled from the padded strips."""
         k = self.last if k is None else k
         self.wait(k)
-        n = self.rows_max * self.width
-        parts = [self.recv[k][r * n: r * n + (self.bounds[r + 1] - self.bounds[r]) * self.width] for r in range(self.world)]
-        return self.torch.cat(parts, dim=0)
+        stacked = self.recv[k].reshape(self.part.world, *self.shape)
+        parts = [self.part.cut(stacked[r], 0, self.part.sizes()[r]) for r in range(self.part.world)]
+        return self.torch.cat(parts, dim=1 if self.part.axis == "cols" else 0).reshape(self.part.height * self.part.width, 4)

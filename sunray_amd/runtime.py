@@ -205,6 +205,14 @@ class Scene:
                                                  C.c_uint32(len(out)), C.byref(n)))
         return out[:n.value]
 
+    def tile_costs(self, which, width, y0, rows):
+        """Measured cycles of every 8x8 tile (row-major, ty * tiles_x + tx) of the last full-width launch of pass `which`."""
+        out = np.zeros(((width + 7) // 8) * ((rows + 7) // 8), dtype=np.uint32)
+        n = C.c_uint32()
+        check(lib().sr_scene_read_tile_costs(self._h, C.c_int(which), C.c_uint32(width), C.c_uint32(y0), C.c_uint32(rows), _p(out),
+                                             C.c_uint32(len(out)), C.byref(n)))
+        return out[:n.value]
+
     def force_next_op(self, op):
         check(lib().sr_scene_force_next_op(self._h, C.c_uint32(op)))
 
@@ -294,8 +302,10 @@ class Scene:
         p.frame_count = frame_count
         p.use_srgb = 0
         p.width, p.height = frame.width, frame.height
-        if tile:
-            p.tile_y0, p.tile_h = tile
+        if tile:                      # (y0, h) rows, or (y0, h, x0, w) rows x columns; h == 0 / w == 0: all of them
+            p.tile_y0, p.tile_h = tile[0], tile[1]
+            if len(tile) == 4:
+                p.tile_x0, p.tile_w = tile[2], tile[3]
         p.config = config or abi.SrTraceConfig.reference()
         return p
 

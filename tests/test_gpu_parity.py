@@ -775,19 +775,68 @@ def test_device_lbvh_fast_build(rt, oracle, blue_noise, scene_fn, box):
 
 def test_4k_frame_1m_triangles(rt, oracle, blue_noise):
     """BASELINE.json config 5's extent (3840x2160) on the 1M-triangle scene: one full frame against the oracle, bit for
-    bit, plus the row-strip composition a tile-parallel run relies on (strip + halo launches == one full launch)."""
+    bit, plus the strip composition a tile-parallel run relies on (strip + halo launches == one full launch), for the
+    column strips bench.py cuts across GPUs and for row strips."""
     desc = scenes.heightfield(708)
     W, H = 3840, 2160
     osc, gsc, of, gf = run_both(rt, oracle, desc, W, H, 1, blue_noise)
     full = gf.host()["raw_color"].copy()
     assert np.isfinite(full).all() and full[:, :3].any()
+    single = gsc.counters()
     from sunray_amd import distributed as sd
-    gf2 = rt.DeviceFrame(W, H, blue_noise)
     m = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H)
     cfg = abi.SrTraceConfig.reference()
-    for rank in range(4):
-        sd.render_strip(gsc, gf2, m, 0, cfg, 4, rank)
-    assert_bits_equal(full, gf2.host()["raw_color"], "4 strips (+halo) compose to the 4K frame")
+    for axis, world in (("cols", 8), ("rows", 4)):
+        gf2 = rt.DeviceFrame(W, H, blue_noise)
+        part = sd.Partition(W, H, world, axis)
+        gsc.reset_counters()
+        for rank in range(world):
+            sd.render_strip(gsc, gf2, m, 0, cfg, part, rank)
+        assert_bits_equal(full, gf2.host()["raw_color"], "%d %s strips (+halo) compose to the 4K frame" % (world, axis))
+        c = gsc.counters()      # halo pixels are traced but not counted: the strips' rays add up to the single launch's
+        assert (c.closest_queries, c.any_queries) == (single.closest_queries, single.any_queries)
+        del gf2
+
+
+def test_column_tiles_compose_and_count(rt, oracle, blue_noise):
+    """Launch rectangles (tile_y0, tile_h, tile_x0, tile_w) with ragged column cuts on a ragged extent: any tiling gives the
+    full launch's bits; count_x0 / count_cols restrict the ray counters to a column window; a tile outside the image is an error."""
+    desc = scenes.cornell_box()
+    W, H = 203, 77
+    osc, gsc, of, gf = run_both(rt, oracle, desc, W, H, 2, blue_noise)         # frames 0, 1 (temporal reuse on frame 1)
+    ref = gf.host()
+    gf2 = rt.DeviceFrame(W, H, blue_noise)
+    prev = None
+    for f in range(2):
+        m = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, prev)
+        prev = list(m.view_proj)
+        cuts = [(0, 0, 0, 61), (0, 0, 61, 3), (0, 40, 64, 139), (40, 37, 64, 139)]      # h == 0: all rows
+        for tile in cuts:
+            gsc.trace_ris(gf2, m, f, tile=tile)
+        for tile in cuts[::-1]:
+            gsc.trace_final(gf2, m, f, tile=tile)
+    got = gf2.host()
+    assert_bits_equal(ref["raw_color"], got["raw_color"], "column tiles raw_color")
+    assert_bits_equal(ref["reservoirs"][1], got["reservoirs"][1], "column tiles reservoirs")
+    assert_bits_equal(ref["reservoirs_gi"][1], got["reservoirs_gi"][1], "column tiles GI reservoirs")
+    # counting window == oracle's
+    cfg = abi.SrTraceConfig.reference()
+    cfg.count_x0, cfg.count_cols, cfg.count_y0, cfg.count_rows = 50, 70, 10, 30
+    m = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H)
+    om = oracle.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H)
+    gsc.reset_counters(); osc.reset_counters()
+    gsc.trace_ris(gf2, m, 0, cfg, tile=(0, 60, 20, 150)); osc.trace_ris(of, om, 0, cfg, tile=(0, 60, 20, 150))
+    gsc.trace_final(gf2, m, 0, cfg, tile=(0, 60, 20, 150)); osc.trace_final(of, om, 0, cfg, tile=(0, 60, 20, 150))
+    gc, oc = gsc.counters(), osc.counters()
+    assert (gc.closest_queries, gc.any_queries) == (oc.closest_queries, oc.any_queries) and 0 < gc.closest_queries < single_frame_closest(osc, of, om)
+    with pytest.raises(Exception):
+        gsc.trace_ris(gf2, m, 0, tile=(0, 0, W, 8))
+
+
+def single_frame_closest(osc, of, om):
+    osc.reset_counters()
+    osc.trace_ris(of, om, 0); osc.trace_final(of, om, 0)
+    return osc.counters().closest_queries
 
 
 def test_device_lbvh_1m_triangles(rt, oracle):

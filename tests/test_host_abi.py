@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_struct_sizes_match_header():
-    assert C.sizeof(abi.SrRtParams) == 160 and C.sizeof(abi.SrTraceConfig) == 32 and C.sizeof(abi.SrMatrices) == 256
+    assert C.sizeof(abi.SrRtParams) == 176 and C.sizeof(abi.SrTraceConfig) == 40 and C.sizeof(abi.SrMatrices) == 256
     cfg = abi.SrTraceConfig()
     _lib.lib().sr_trace_config_default(C.byref(cfg))
     ref = abi.SrTraceConfig.reference()
