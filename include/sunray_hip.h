@@ -355,6 +355,11 @@ int sr_scene_remove(SrScene* scene, uint64_t key);
  * pointer, w*h*channels bytes. Returns the image slot materials refer to (Material::*_image). */
 int sr_scene_add_image(SrScene* scene, const uint8_t* data, uint32_t width, uint32_t height, uint32_t channels,
                        uint32_t* out_image_slot);
+/* Frees an image added with sr_scene_add_image (ResourceManager::remove drops a key's images with its BLAS,
+ * resource_manager.rs:459-472); the slot is handed out again by a later sr_scene_add_image. SR_ERR_STATE while a registered
+ * mesh's material still names the slot. Waits for the device. */
+int sr_scene_remove_image(SrScene* scene, uint32_t image_slot);
+
 /* Sampler::new (image/sampler.rs:44-67). Returns the sampler slot (Material::*_sampler). */
 int sr_scene_add_sampler(SrScene* scene, const SrSamplerDesc* desc, uint32_t* out_sampler_slot);
 /* ResourceManager::frame_instance_data (resource_manager.rs:216-267) + the dummy-entry padding of
@@ -424,6 +429,13 @@ int sr_trace_any(const SrScene* scene, const SrRay* rays, uint32_t n, uint32_t* 
 int sr_shade_closest_hit(const SrScene* scene, const SrHit* hits, uint32_t n, SrRayPayload* payloads,
                          void* stream);
 
+/* any_hit (any_hit.slang:11-43) applied to hit records: ignored[i] = 1 where the shader would call IgnoreHit() (the
+ * mesh's material has alpha_mode != 0 and the base-colour alpha sampled at the hit's interpolated uv is below
+ * alpha_cutoff), else 0. The traversal never runs it: every BLAS geometry carries the OPAQUE flag (blas.rs:276) and
+ * Material::new forces alpha_mode = 0 (material.rs:74) — this hook exists so that the shader's lines have a device
+ * counterpart with a parity test. Misses (t < 0) give 0. Device pointers. */
+int sr_any_hit_ignores(const SrScene* scene, const SrHit* hits, uint32_t n, uint32_t* ignored, void* stream);
+
 /* The "raytracing_ris" pass (lib.rs:1662-1705): one ray_gen_ris invocation per pixel
  * (ray_gen_ris.slang:12-440): G-buffer + ReSTIR-DI reservoir + ReSTIR-GI initial reservoir. */
 int sr_trace_ris(const SrRtParams* params, void* stream);
@@ -481,6 +493,17 @@ int sr_renderer_destroy(SrRenderer* renderer);
 /* Renderer::resize (lib.rs:586-639): waits for the device, recreates every image at the new extent,
  * relative_frame_count = 0. Same extent: no-op (lib.rs:598-600). */
 int sr_renderer_resize(SrRenderer* renderer, uint32_t width, uint32_t height);
+
+/* Frame / resize callbacks (src/lib.rs:537-554). A start-of-frame callback runs once, on the caller's thread, at the
+ * start of the next sr_renderer_render (before any per-frame work); an end-of-frame callback runs once the next
+ * rendered frame has COMPLETED ON THE GPU — checked at the start of later sr_renderer_render calls, as the reference
+ * drains them there (lib.rs:1004-1010) — the deferred-deallocation hook; a resize callback is persistent and runs on
+ * every sr_renderer_resize call with the new extent (lib.rs:586-594). Callbacks run in registration order. */
+typedef void (*SrFrameCallback)(void* user);
+typedef void (*SrResizeCallback)(void* user, uint32_t width, uint32_t height);
+int sr_renderer_add_start_of_frame_callback(SrRenderer* renderer, SrFrameCallback callback, void* user);
+int sr_renderer_add_end_of_frame_callback(SrRenderer* renderer, SrFrameCallback callback, void* user);
+int sr_renderer_add_resize_callback(SrRenderer* renderer, SrResizeCallback callback, void* user);
 /* Renderer::load_mesh (lib.rs:873-954); host pointers. */
 int sr_renderer_load_mesh(SrRenderer* renderer, uint64_t key, const SrVertex* vertices, uint32_t n_vertices,
                           const uint32_t* indices, uint32_t n_indices, const SrMaterial* material);

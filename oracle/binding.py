@@ -205,6 +205,11 @@ class OracleScene:
         lib().orc_shade_closest_hit(self._h, _p(hits), C.c_uint32(len(hits)), _p(out))
         return out
 
+    def any_hit_ignores(self, hits):
+        out = np.zeros(len(hits), dtype=np.uint32)
+        lib().orc_any_hit(self._h, _p(hits), C.c_uint32(len(hits)), _p(out))
+        return out
+
     def _params(self, frame, matrices, frame_count, config, tile=None):
         p = abi.SrRtParams()
         p.scene = None

@@ -133,6 +133,13 @@ void orc_eval_unshadowed_light(const float* hp, const float* hn, const float* vv
                                  rough, metal, v3(emission[0], emission[1], emission[2]), v3(lp[0], lp[1], lp[2]), v3(ln[0], ln[1], ln[2]));
     o[0] = f.x; o[1] = f.y; o[2] = f.z;
 }
+float orc_gi_target_pdf(const float* sp, const float* sn, const float* alb, float metallic, const float* xp, const float* rad) {
+    return gi_target_pdf(v3(sp[0], sp[1], sp[2]), v3(sn[0], sn[1], sn[2]), v3(alb[0], alb[1], alb[2]), metallic, v3(xp[0], xp[1], xp[2]), v3(rad[0], rad[1], rad[2]));
+}
+void orc_merge_reservoirs(SrReservoir* r, const SrReservoir* new_r, float p_hat_new, float random_val) { merge_reservoirs(*r, *new_r, p_hat_new, random_val); }
+void orc_merge_reservoirs_gi(SrReservoirGI* r, const SrReservoirGI* new_r, float p_hat_new, float jacobian, float random_val) {
+    merge_reservoirs_gi(*r, *new_r, p_hat_new, jacobian, random_val);
+}
 float orc_smith_v_ggx(float a, float b, float c) { return smith_v_ggx(a, b, c); }
 float orc_smith_g1_ggx(float a, float b) { return smith_g1_ggx(a, b); }
 float orc_smoothstep(float a, float b, float x) { return smoothstep(a, b, x); }
@@ -143,6 +150,12 @@ void orc_reflect(const float* i, const float* n, float* o) { V3 r = reflect(v3(i
 int orc_any_hit_ignores(uint32_t alpha_mode, float alpha_cutoff, float base_alpha) {
     if (alpha_mode == 0) return 0;
     return base_alpha < alpha_cutoff ? 1 : 0;
+}
+// The whole shader on hit records (the CPU side of sr_any_hit_ignores): MeshInfo -> indices -> vertices -> uv ->
+// sample_texture -> alpha test, any_hit.slang:14-42.
+void orc_any_hit(void* sp, const SrHit* hits, uint32_t n, uint32_t* ignored) {
+    Scene* s = (Scene*)sp;
+    for (uint32_t i = 0; i < n; i++) ignored[i] = s->any_hit_ignores(Hit{hits[i].t, hits[i].u, hits[i].v, hits[i].t < 0.0f ? 0xFFFFFFFFu : hits[i].tri}) ? 1u : 0u;
 }
 // the canonical triangle test, for direct unit tests
 int orc_intersect_tri(const float* o, const float* d, const float* v0, const float* v1, const float* v2, float tmin, float tmax, float* tuv) {

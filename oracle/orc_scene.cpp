@@ -456,6 +456,24 @@ bool Scene::any_bvh(V3 o, V3 d, float tmin, float tmax, Counters* c) const {
 // K4 closest_hit (closest_hit.slang:12-91) and K6 ray_miss (ray_miss.slang:10-13).
 // Textures go through Scene::sample_texture (orc_texture.h).
 // ---------------------------------------------------------------------------------------------
+bool Scene::any_hit_ignores(const Hit& h) const {
+    if (h.tri == 0xFFFFFFFFu || h.tri >= tris.size()) return false;
+    const WTri& wt = tris[h.tri];
+    const Mesh& mesh = meshes[instances[wt.instance].mesh_slot];                      // meshes[InstanceID()], :14-15
+    const SrMaterial& m = mesh.material;
+    if (m.alpha_mode == 0) return false;                                              // :20-22
+    V3 bary = v3(1.0f - h.u - h.v, h.u, h.v);                                         // :24-26
+    uint32_t io = wt.prim * 3;                                                        // :28-31
+    const SrVertex& a = mesh.vertices[mesh.indices[io + 0]];
+    const SrVertex& b = mesh.vertices[mesh.indices[io + 1]];
+    const SrVertex& c = mesh.vertices[mesh.indices[io + 2]];
+    float uv_s = (a.base_color_tex_coord[0] * bary.x + b.base_color_tex_coord[0] * bary.y) + c.base_color_tex_coord[0] * bary.z;   // :33-36
+    float uv_t = (a.base_color_tex_coord[1] * bary.x + b.base_color_tex_coord[1] * bary.y) + c.base_color_tex_coord[1] * bary.z;
+    V4 base_color = sample_texture(m.base_color_image, m.base_color_sampler, uv_s, uv_t,
+                                   V4{m.base_color_value[0], m.base_color_value[1], m.base_color_value[2], m.base_color_value[3]});    // :38
+    return base_color.w < m.alpha_cutoff;                                             // :40-42
+}
+
 SrRayPayload Scene::shade_hit(const Hit& h) const {
     SrRayPayload pl;
     memset(&pl, 0, sizeof(pl));

@@ -90,6 +90,7 @@ struct Scene {
     }
     // closest_hit.slang:12-91 / ray_miss.slang:10-13
     SrRayPayload shade_hit(const Hit& h) const;
+    bool any_hit_ignores(const Hit& h) const;   // any_hit.slang:11-43
 };
 
 // H1/H2: camera.rs:33-63 + lib.rs:1017-1048

@@ -13,10 +13,10 @@ _lib = None
 SYMBOLS = [
     "sr_last_error", "sr_version", "sr_camera_matrices", "sr_material_new", "sr_emissive_triangles_from_mesh",
     "sr_trace_config_default", "sr_scene_create", "sr_scene_destroy", "sr_as_state_initial", "sr_as_state_next_op", "sr_as_state_mark_built", "sr_scene_as_state", "sr_scene_end_frame",
-    "sr_bvh_layout", "sr_scene_read_bvh", "sr_scene_force_next_op", "sr_scene_add_mesh", "sr_scene_add_blas", "sr_scene_remove", "sr_scene_add_image", "sr_scene_add_sampler", "sr_scene_set_instances",
+    "sr_bvh_layout", "sr_scene_read_bvh", "sr_scene_force_next_op", "sr_scene_add_mesh", "sr_scene_add_blas", "sr_scene_remove", "sr_scene_add_image", "sr_scene_remove_image", "sr_scene_add_sampler", "sr_scene_set_instances",
     "sr_scene_get_tables", "sr_scene_bvh_stats", "sr_scene_resolve_triangle", "sr_host_bvh_build", "sr_host_bvh_get",
-    "sr_host_bvh_destroy", "sr_trace_closest", "sr_trace_any", "sr_shade_closest_hit", "sr_trace_ris", "sr_trace_final", "sr_post_temporal", "sr_post_denoise", "sr_post_tonemap", "sr_renderer_create", "sr_renderer_destroy",
-    "sr_renderer_resize", "sr_renderer_load_mesh", "sr_renderer_set_config", "sr_renderer_render", "sr_renderer_wait_frame",
+    "sr_host_bvh_destroy", "sr_trace_closest", "sr_trace_any", "sr_shade_closest_hit", "sr_any_hit_ignores", "sr_trace_ris", "sr_trace_final", "sr_post_temporal", "sr_post_denoise", "sr_post_tonemap", "sr_renderer_create", "sr_renderer_destroy",
+    "sr_renderer_resize", "sr_renderer_add_start_of_frame_callback", "sr_renderer_add_end_of_frame_callback", "sr_renderer_add_resize_callback", "sr_renderer_load_mesh", "sr_renderer_set_config", "sr_renderer_render", "sr_renderer_wait_frame",
     "sr_renderer_render_to_host_memory", "sr_renderer_get", "sr_gltf_open", "sr_gltf_close", "sr_gltf_counts", "sr_gltf_blas", "sr_gltf_instance", "sr_gltf_image",
     "sr_gltf_sampler", "sr_gltf_texture", "sr_renderer_load_gltf", "sr_renderer_load_scene", "sr_loaded_scene_get", "sr_loaded_scene_destroy",
     "sr_renderer_unload_scene", "sr_renderer_unload_mesh", "sr_default_noise_texture",

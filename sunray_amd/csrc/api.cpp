@@ -3,6 +3,8 @@
 // the host-side data preparation (host_prep.cpp, bvh_build.cpp) and the HIP kernels (kernels.hip).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -67,6 +69,9 @@ struct DeviceBuffer {
 
 }  // namespace
 
+constexpr size_t kQueueHeadOffset = 256;   // d_misc: [0,32) ray counters, [64,128) diagnostics, [256, 256 + 16 * kQueueHeads) queue heads
+constexpr uint32_t kQueueHeads = 64;
+
 struct SrScene {
     int device = 0;
     std::vector<srh::HostMesh> meshes;
@@ -78,7 +83,8 @@ struct SrScene {
     srh::FrameInstanceData fid;
     std::vector<srh::BuildTri> world_tris;
     struct DeviceImage { void* d_texels = nullptr; uint32_t w = 0, h = 0; };
-    std::vector<DeviceImage> images;        // image slot order (Material::*_image)
+    std::vector<DeviceImage> images;        // image slot order (Material::*_image); a removed image leaves d_texels == nullptr
+    std::vector<uint32_t> free_image_slots; // slots of removed images, reused by the next sr_scene_add_image
     std::vector<SrSamplerDesc> samplers;    // sampler slot order (Material::*_sampler)
     DeviceBuffer d_nodes, d_tris, d_shade, d_mesh_const, d_slot_of_gid, d_instances, d_lights, d_misc;
     DeviceBuffer d_shade_tex, d_mesh_tex, d_textures;
@@ -88,6 +94,7 @@ struct SrScene {
     struct TileSchedule { int which = -1; uint32_t width = 0 /* columns of the launch rectangle */, y0 = 0, y1 = 0, x0 = 0; DeviceBuffer cost, order; bool have_order = false; uint64_t last_use = 0; uint32_t uses = 0; };
     std::vector<TileSchedule> schedules;
     uint64_t schedule_clock = 0;
+    uint32_t queue_head_clock = 0;          // next entry of the queue-head ring (trace_queue)
     int tile_scheduling = 1;                // SR_TILE_SCHEDULING=0 in the environment disables it (A/B)
     int fast_build_ploc = 16;               // device fast build: PLOC with this search radius (default), 0 = radix tree (SR_FAST_BUILD=lbvh | ploc<r>)
     uint32_t forced_op = SR_OP_NONE;        // sr_scene_force_next_op (test / bench hook)
@@ -163,6 +170,7 @@ int sr_emissive_triangles_from_mesh(const SrVertex* vertices, uint32_t n_vertice
                                     uint32_t n_indices, const SrMaterial* material, SrEmissiveTriangle* out,
                                     uint32_t cap, uint32_t* out_count) {
     if (!vertices || !indices || !material || !out_count) return fail(SR_ERR_INVALID_ARG, "sr_emissive_triangles_from_mesh: null argument");
+    if (!out && cap > 0) return fail(SR_ERR_INVALID_ARG, "sr_emissive_triangles_from_mesh: out is null but cap > 0 (pass cap = 0 to query the count)");
     for (uint32_t i = 0; i < n_indices; i++)
         if (indices[i] >= n_vertices) return fail(SR_ERR_INVALID_ARG, "sr_emissive_triangles_from_mesh: index out of range");
     std::vector<SrEmissiveTriangle> v;
@@ -194,9 +202,9 @@ int sr_scene_create(int device, SrScene** out) {
     if (const char* ev = getenv("SR_FAST_BUILD")) s->fast_build_ploc = !strcmp(ev, "lbvh") ? 0 : (!strncmp(ev, "ploc", 4) && atoi(ev + 4) > 0 ? atoi(ev + 4) : 16);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
-    // counters (4 x u64) + queue head, in one small allocation of their own
-    const unsigned long long zeros[32] = {0};
-    int rc = s->d_misc.upload(zeros, sizeof(zeros));
+    // counters (4 x u64), diagnostics and the ring of queue heads, in one small allocation of their own
+    const std::vector<unsigned char> zeros(kQueueHeadOffset + 16 * kQueueHeads, 0);
+    int rc = s->d_misc.upload(zeros.data(), zeros.size());
     if (rc != SR_OK) { delete s; return rc; }
     *out = s;
     return SR_OK;
@@ -234,6 +242,14 @@ int sr_scene_add_blas(SrScene* s, uint64_t key, const SrVertex* vertices, uint32
         if (indices[i] >= n_vertices) {
             char buf[120];
             snprintf(buf, sizeof(buf), "load_mesh: index %u out of range for %u vertices", indices[i], n_vertices);
+            return fail(SR_ERR_INVALID_ARG, buf);
+        }
+    // Vulkan treats a triangle with a NaN position as inactive; the builders quantise positions (a non-finite one would
+    // be undefined behaviour there), so such meshes are refused instead
+    for (uint32_t i = 0; i < n_vertices; i++)
+        if (!std::isfinite(vertices[i].position[0]) || !std::isfinite(vertices[i].position[1]) || !std::isfinite(vertices[i].position[2])) {
+            char buf[120];
+            snprintf(buf, sizeof(buf), "load_mesh: vertex %u has a non-finite position", i);
             return fail(SR_ERR_INVALID_ARG, buf);
         }
     const uint32_t* tex = &material->base_color_image;   // five (image, sampler) slot pairs (resources/material.rs:33-42)
@@ -335,9 +351,33 @@ int sr_scene_add_image(SrScene* s, const uint8_t* data, uint32_t width, uint32_t
     SrScene::DeviceImage im;
     im.w = width; im.h = height;
     HIP_TRY(hipMalloc(&im.d_texels, n * 4));
-    HIP_TRY(hipMemcpy(im.d_texels, rgba.data(), n * 4, hipMemcpyHostToDevice));
-    s->images.push_back(im);
-    if (out_image_slot) *out_image_slot = (uint32_t)s->images.size() - 1;
+    const hipError_t ce = hipMemcpy(im.d_texels, rgba.data(), n * 4, hipMemcpyHostToDevice);
+    if (ce != hipSuccess) { (void)hipFree(im.d_texels); return fail(SR_ERR_HIP, std::string("Image::new_from_data: ") + hipGetErrorString(ce)); }
+    uint32_t slot;
+    if (!s->free_image_slots.empty()) { slot = s->free_image_slots.back(); s->free_image_slots.pop_back(); s->images[slot] = im; }
+    else { slot = (uint32_t)s->images.size(); s->images.push_back(im); }
+    if (out_image_slot) *out_image_slot = slot;
+    return SR_OK;
+}
+
+// ResourceManager::remove drops a group's images with its BLASes (resource_manager.rs:472). The caller must have removed
+// (or be about to remove) every mesh whose material names the slot; meshes still naming it are rejected at the next
+// sr_scene_set_instances. Waits for the device: a launch in flight may still sample the texels.
+int sr_scene_remove_image(SrScene* s, uint32_t image_slot) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_remove_image: scene is null");
+    if (image_slot >= s->images.size() || !s->images[image_slot].d_texels) return fail(SR_ERR_INVALID_ARG, "sr_scene_remove_image: no image in this slot");
+    for (const auto& m : s->meshes) {
+        if (m.n_vertices == 0) continue;
+        const uint32_t* tex = &m.material.base_color_image;
+        for (int i = 0; i < 10; i += 2)
+            if (tex[i] == image_slot) return fail(SR_ERR_STATE, "sr_scene_remove_image: a registered mesh still uses this image (remove the mesh first)");
+    }
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(s->images[image_slot].d_texels));
+    s->images[image_slot] = SrScene::DeviceImage();
+    s->free_image_slots.push_back(image_slot);
     return SR_OK;
 }
 
@@ -412,6 +452,7 @@ int upload_mesh_tables(SrScene* s, bool* any_textured_out) {
         memcpy(t.emissive_factor, m.emissive_factor, 12);
         t.emissive_strength = m.emissive_factor[3];
         t.roughness = m.roughness_factor; t.metallic = m.metallic_factor;
+        t.alpha_mode = m.alpha_mode; t.alpha_cutoff = m.alpha_cutoff;
         t.img_base = m.base_color_image; t.img_mr = m.metallic_roughness_image; t.img_normal = m.normal_image; t.img_emissive = m.emissive_image;
         t.samplers = sampler_code(m.base_color_image, m.base_color_sampler) | (sampler_code(m.metallic_roughness_image, m.metallic_roughness_sampler) << 8) |
                      (sampler_code(m.normal_image, m.normal_sampler) << 16) | (sampler_code(m.emissive_image, m.emissive_sampler) << 24);
@@ -520,6 +561,19 @@ int fast_build(SrScene* s) {
 
 int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* counts, uint32_t n_keys, const SrTransform* transforms) {
     if (!s || (n_keys && (!keys || !counts))) return fail(SR_ERR_INVALID_ARG, "frame_instance_data: null argument");
+    // sizes first, in 64 bits: the per-instance triangle offsets are 32-bit sums and a leaf reference holds 28 bits
+    uint64_t n_inst = 0, n_tri = 0;
+    for (uint32_t k = 0; k < n_keys; k++) {
+        n_inst += counts[k];
+        auto it = s->slots.find(keys[k]);
+        if (it != s->slots.end()) n_tri += (uint64_t)counts[k] * (s->meshes[it->second].n_indices / 3);
+    }
+    if (n_inst && !transforms) return fail(SR_ERR_INVALID_ARG, "frame_instance_data: transforms is null but instances were given");
+    if (n_tri >= (1ull << 28)) return fail(SR_ERR_UNSUPPORTED, "scene exceeds 2^28 triangles (leaf reference encoding)");
+    if (n_inst >= (1ull << 31)) return fail(SR_ERR_UNSUPPORTED, "scene exceeds 2^31 instances");
+    for (uint64_t i = 0; i < n_inst; i++)
+        for (int c = 0; c < 12; c++)
+            if (!std::isfinite(transforms[i].m[c])) return fail(SR_ERR_INVALID_ARG, "frame_instance_data: instance transform holds a non-finite value");
     int rc = bind_device(s);
     if (rc != SR_OK) return rc;
     std::string err;
@@ -721,8 +775,10 @@ static int trace_queue(SrScene* s, const SrRay* rays, uint32_t n, SrHit* hits, u
     if (n && (!rays || (any ? (void*)occluded : (void*)hits) == nullptr)) return fail(SR_ERR_INVALID_ARG, "sr_trace: null ray/output pointer");
     int rc = bind_device(s);
     if (rc != SR_OK) return rc;
+    if (n > (1u << 31)) return fail(SR_ERR_UNSUPPORTED, "sr_trace: more than 2^31 rays in one call (the queue head is a 32-bit counter)");
     hipStream_t st = (hipStream_t)stream;
-    uint32_t* queue_head = (uint32_t*)((char*)s->d_misc.p + 32);
+    // every launch gets a queue head of its own from a small ring, so launches on different streams never share one
+    uint32_t* queue_head = (uint32_t*)((char*)s->d_misc.p + kQueueHeadOffset + 16 * (s->queue_head_clock++ % kQueueHeads));
     const int lds_per_block = srk_lds_rows(s->stack_entries) * 256 * 4;
     int per_cu = std::max(1, std::min(8, 160 * 1024 / lds_per_block));  // persistent grid = LDS-limited residency
     if (const char* e = getenv("SR_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));   // tuning switch
@@ -748,6 +804,17 @@ int sr_shade_closest_hit(const SrScene* s, const SrHit* hits, uint32_t n, SrRayP
     if (rc != SR_OK) return rc;
     int e = srk_launch_shade(s->dev, hits, n, payloads, (hipStream_t)stream);
     if (e != 0) return fail(SR_ERR_HIP, std::string("shade kernel launch: ") + hipGetErrorString((hipError_t)e));
+    return SR_OK;
+}
+
+int sr_any_hit_ignores(const SrScene* s, const SrHit* hits, uint32_t n, uint32_t* ignored, void* stream) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_any_hit_ignores: scene is null");
+    if (!s->built) return fail(SR_ERR_STATE, "sr_any_hit_ignores: scene not built");
+    if (n && (!hits || !ignored)) return fail(SR_ERR_INVALID_ARG, "sr_any_hit_ignores: null pointer");
+    int rc = bind_device(s);
+    if (rc != SR_OK) return rc;
+    int e = srk_launch_any_hit(s->dev, hits, n, ignored, (hipStream_t)stream);
+    if (e != 0) return fail(SR_ERR_HIP, std::string("any_hit kernel launch: ") + hipGetErrorString((hipError_t)e));
     return SR_OK;
 }
 
@@ -808,7 +875,7 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
             if (s->schedules.size() < 8) s->schedules.emplace_back();
             sched = &s->schedules[0];
             for (auto& ts : s->schedules) if (ts.which < 0 || ts.last_use < sched->last_use) sched = &ts;
-            if (sched->which >= 0) HIP_TRY(hipStreamSynchronize(st));          // recycling an entry a launch may still read
+            if (sched->which >= 0) HIP_TRY(hipDeviceSynchronize());            // recycling an entry a launch on ANY stream may still read
             const size_t bytes = (size_t)srk_pass_tile_count(cols, y1 - y0) * 4;
             if ((rc = sched->cost.reserve(bytes)) != SR_OK || (rc = sched->order.reserve((size_t)srk_pass_order_cap(cols, y1 - y0) * 8 * 4)) != SR_OK) return rc;
             HIP_TRY(hipMemsetAsync(sched->cost.p, 0, bytes, st));

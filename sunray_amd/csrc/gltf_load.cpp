@@ -198,6 +198,8 @@ bool decode_png(const uint8_t* d, size_t n, DecodedImage& out, std::string& err)
     int samples = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!samples || (depth != 8 && depth != 4 && depth != 2 && depth != 1) || (depth < 8 && ctype != 0 && ctype != 3)) { err = "image: unsupported PNG colour type / bit depth"; return false; }
     const size_t bpp_bits = (size_t)samples * depth, stride = ((size_t)w * bpp_bits + 7) / 8, bpp = (bpp_bits + 7) / 8;
+    // deflate expands at most ~1032:1: refuse a header that promises more than the IDAT bytes can hold before allocating for it
+    if ((stride + 1) * (size_t)h > idat.size() * 1032 + 65536) { err = "image: PNG IDAT data too short for the extent in its header"; return false; }
     std::vector<uint8_t> raw((stride + 1) * h);
     uLongf raw_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) { err = "image: PNG inflate failed"; return false; }

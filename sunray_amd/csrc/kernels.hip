@@ -83,6 +83,14 @@ __global__ __launch_bounds__(kBlock) void shade_closest_hit_kernel(DevScene sc, 
     out[i] = o;
 }
 
+__global__ __launch_bounds__(kBlock) void any_hit_kernel(DevScene sc, const SrHit* __restrict__ hits, uint32_t n, uint32_t* __restrict__ ignored) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const SrHit h = hits[i];
+    const bool hit = !(h.t < 0.0f) && h.tri < sc.n_tris;
+    ignored[i] = (hit && any_hit_ignores(sc, sc.slot_of_gid[h.tri], h.u, h.v)) ? 1u : 0u;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-pixel passes
 // ---------------------------------------------------------------------------------------------
@@ -947,6 +955,12 @@ int srk_launch_trace(const DevScene& sc, const SrRay* rays, uint32_t n, SrHit* h
 int srk_launch_shade(const DevScene& sc, const SrHit* hits, uint32_t n, SrRayPayload* out, hipStream_t stream) {
     if (n == 0) return 0;
     shade_closest_hit_kernel<<<dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream>>>(sc, hits, n, out);
+    return (int)hipGetLastError();
+}
+
+int srk_launch_any_hit(const DevScene& sc, const SrHit* hits, uint32_t n, uint32_t* ignored, hipStream_t stream) {
+    if (n == 0) return 0;
+    any_hit_kernel<<<dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream>>>(sc, hits, n, ignored);
     return (int)hipGetLastError();
 }
 

@@ -42,9 +42,16 @@ struct SrRenderer {
     std::vector<uint32_t> last_counts;
     std::vector<SrTransform> last_transforms;
     bool instances_valid = false;
-    // asset groups of load_scene (lib.rs:802-828): group -> BLAS keys; images stay resident (slots are never reused)
+    // asset groups of load_scene (lib.rs:802-828): group -> BLAS keys and image slots (both freed by unload_scene)
     uint64_t next_group = 0;
     std::map<uint64_t, std::vector<uint64_t>> scene_groups;
+    std::map<uint64_t, std::vector<uint32_t>> scene_images;
+    // frame / resize callbacks (lib.rs:537-554): (due frame, fn, user); start-of-frame and end-of-frame ones run once
+    struct FrameCb { uint64_t frame; SrFrameCallback fn; void* user; };
+    std::vector<FrameCb> start_of_frame_callbacks, end_of_frame_callbacks;
+    std::vector<std::pair<SrResizeCallback, void*>> resize_callbacks;
+    uint64_t frame_of_set[2] = {0, 0};       // absolute frame number last rendered into image set k (its completion = ev_done[k])
+    uint64_t completed_frame = 0;            // highest frame known complete on the GPU (frames complete in order)
     std::map<std::array<uint32_t, 4>, uint32_t> sampler_slots;   // dedup like ResourceManager::sampler_slot (resource_manager.rs:491-499)
     int default_sampler = -1;                                    // LINEAR / CLAMP_TO_EDGE (resource_manager.rs:128-136)
 };
@@ -153,15 +160,58 @@ int sr_renderer_destroy(SrRenderer* r) {
 // Renderer::resize (lib.rs:586-639): new temporal resources, relative_frame_count = 0
 int sr_renderer_resize(SrRenderer* r, uint32_t width, uint32_t height) {
     if (!r || width == 0 || height == 0) return rfail(SR_ERR_INVALID_ARG, "Renderer::resize: bad argument");
-    if (width == r->width && height == r->height) return SR_OK;   // lib.rs:598-600
-    R_HIP(hipSetDevice(r->device));
-    R_HIP(hipDeviceSynchronize());                                // device_wait_idle (lib.rs:604)
-    free_images(r);
-    int rc = alloc_images(r, width, height);
-    if (rc != SR_OK) return rc;
-    r->relative_frame_count = 0;
+    if (!(width == r->width && height == r->height)) {            // resize_internal_images returns early for an unchanged extent (lib.rs:598-600)
+        R_HIP(hipSetDevice(r->device));
+        R_HIP(hipDeviceSynchronize());                            // device_wait_idle (lib.rs:604)
+        free_images(r);
+        int rc = alloc_images(r, width, height);
+        if (rc != SR_OK) return rc;
+        r->relative_frame_count = 0;
+    }
+    for (auto& cb : r->resize_callbacks) cb.first(cb.second, width, height);   // every resize call, changed extent or not (lib.rs:590-592)
     return SR_OK;
 }
+
+// Renderer::add_start_of_frame_callback / add_end_of_frame_callback / add_resize_callback (lib.rs:537-554)
+int sr_renderer_add_start_of_frame_callback(SrRenderer* r, SrFrameCallback fn, void* user) {
+    if (!r || !fn) return rfail(SR_ERR_INVALID_ARG, "add_start_of_frame_callback: null argument");
+    r->start_of_frame_callbacks.push_back({r->absolute_frame_count + 1, fn, user});
+    return SR_OK;
+}
+int sr_renderer_add_end_of_frame_callback(SrRenderer* r, SrFrameCallback fn, void* user) {
+    if (!r || !fn) return rfail(SR_ERR_INVALID_ARG, "add_end_of_frame_callback: null argument");
+    r->end_of_frame_callbacks.push_back({r->absolute_frame_count + 1, fn, user});
+    return SR_OK;
+}
+int sr_renderer_add_resize_callback(SrRenderer* r, SrResizeCallback fn, void* user) {
+    if (!r || !fn) return rfail(SR_ERR_INVALID_ARG, "add_resize_callback: null argument");
+    r->resize_callbacks.push_back({fn, user});
+    return SR_OK;
+}
+
+namespace {
+// run_start_of_frame_callbacks (lib.rs:558-568) and run_due_end_of_frame_callbacks (:572-583), in registration order.
+// A callback may register further callbacks (they are tagged with a later frame and stay queued).
+void run_frame_callbacks(SrRenderer* r, uint64_t upcoming_frame) {
+    for (size_t i = 0; i < r->start_of_frame_callbacks.size();) {
+        if (r->start_of_frame_callbacks[i].frame <= upcoming_frame) {
+            const SrRenderer::FrameCb cb = r->start_of_frame_callbacks[i];
+            r->start_of_frame_callbacks.erase(r->start_of_frame_callbacks.begin() + (long)i);
+            cb.fn(cb.user);
+        } else i++;
+    }
+    // the frame timeline: frames complete in order; a set's ev_done is the completion of the frame last rendered into it
+    for (int k = 0; k < 2; k++)
+        if (r->frame_of_set[k] > r->completed_frame && hipEventQuery(r->ev_done[k]) == hipSuccess) r->completed_frame = r->frame_of_set[k];
+    for (size_t i = 0; i < r->end_of_frame_callbacks.size();) {
+        if (r->end_of_frame_callbacks[i].frame <= r->completed_frame) {
+            const SrRenderer::FrameCb cb = r->end_of_frame_callbacks[i];
+            r->end_of_frame_callbacks.erase(r->end_of_frame_callbacks.begin() + (long)i);
+            cb.fn(cb.user);
+        } else i++;
+    }
+}
+}  // namespace
 
 // Renderer::load_mesh (lib.rs:873-954)
 int sr_renderer_load_mesh(SrRenderer* r, uint64_t key, const SrVertex* vertices, uint32_t n_vertices, const uint32_t* indices,
@@ -186,6 +236,7 @@ int sr_renderer_render(SrRenderer* r, const float cam_pos[3], const float cam_ta
                        const uint32_t* counts, uint32_t n_keys, const SrTransform* transforms, void* stream, uint64_t* out_frame) {
     if (!r || !cam_pos || !cam_target) return rfail(SR_ERR_INVALID_ARG, "Renderer::render: null argument");
     R_HIP(hipSetDevice(r->device));
+    run_frame_callbacks(r, r->absolute_frame_count + 1);            // start of frame (lib.rs:1004-1010)
     // instances: the acceleration structure follows the caller's list — update in place / fast rebuild / settle as
     // AsState decides (tlas.rs:155-191, acceleration_structure/mod.rs:62-148); an identical list is a quiet frame
     uint32_t n_xf = 0;
@@ -243,6 +294,7 @@ int sr_renderer_render(SrRenderer* r, const float cam_pos[3], const float cam_ta
     r->last_set = k;
     r->relative_frame_count += 1;                                    // lib.rs:1438-1439
     r->absolute_frame_count += 1;
+    r->frame_of_set[k] = r->absolute_frame_count;
     if (out_frame) *out_frame = r->absolute_frame_count;
     return SR_OK;
 }
@@ -297,9 +349,15 @@ int sr_renderer_load_scene(SrRenderer* r, const SrGltf* g, SrLoadedScene** out) 
     if (rc != SR_OK) return rc;
     const uint64_t group = r->next_group++;
     std::vector<uint32_t> image_slots(n_images), smp_slots(n_samplers);
+    std::vector<uint32_t>& group_images = r->scene_images[group];     // freed again by unload_scene (also after a failed load)
     for (uint32_t i = 0; i < n_images; i++) {
         const uint8_t* px; uint32_t w, h, ch;
-        if ((rc = sr_gltf_image(g, i, &px, &w, &h, &ch)) != SR_OK || (rc = sr_scene_add_image(r->scene, px, w, h, ch, &image_slots[i])) != SR_OK) return rc;
+        if ((rc = sr_gltf_image(g, i, &px, &w, &h, &ch)) != SR_OK || (rc = sr_scene_add_image(r->scene, px, w, h, ch, &image_slots[i])) != SR_OK) {
+            for (uint32_t sl : group_images) sr_scene_remove_image(r->scene, sl);
+            r->scene_images.erase(group);
+            return rc;
+        }
+        group_images.push_back(image_slots[i]);
     }
     for (uint32_t i = 0; i < n_samplers; i++) {
         SrSamplerDesc d;
@@ -376,14 +434,23 @@ int sr_loaded_scene_get(const SrLoadedScene* ls, uint64_t* group, const uint64_t
 }
 int sr_loaded_scene_destroy(SrLoadedScene* ls) { delete ls; return SR_OK; }
 
-// Renderer::unload_scene (lib.rs:849-857): frees every BLAS the load created; instances of those keys must no
-// longer be passed to render.
+// Renderer::unload_scene (lib.rs:849-857): frees every asset the load created — the BLASes and, as
+// ResourceManager::remove does (resource_manager.rs:459-472), the images; instances of those keys must no longer be
+// passed to render. Loading and unloading a scene repeatedly leaks no HBM.
 int sr_renderer_unload_scene(SrRenderer* r, uint64_t group) {
     if (!r) return rfail(SR_ERR_INVALID_ARG, "unload_scene: renderer is null");
+    R_HIP(hipSetDevice(r->device));
+    R_HIP(hipDeviceSynchronize());                                   // device_wait_idle (lib.rs:850)
     auto it = r->scene_groups.find(group);
-    if (it == r->scene_groups.end()) return SR_OK;
-    for (uint64_t k : it->second) { int rc = sr_scene_remove(r->scene, k); if (rc != SR_OK) return rc; }
-    r->scene_groups.erase(it);
+    if (it != r->scene_groups.end()) {
+        for (uint64_t k : it->second) { int rc = sr_scene_remove(r->scene, k); if (rc != SR_OK) return rc; }
+        r->scene_groups.erase(it);
+    }
+    auto im = r->scene_images.find(group);
+    if (im != r->scene_images.end()) {
+        for (uint32_t sl : im->second) { int rc = sr_scene_remove_image(r->scene, sl); if (rc != SR_OK) return rc; }
+        r->scene_images.erase(im);
+    }
     r->instances_valid = false;
     return SR_OK;
 }

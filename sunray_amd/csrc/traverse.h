@@ -44,13 +44,15 @@ struct DevMeshConst {  // 32 B: the per-mesh constants of the 32-byte RayPayload
 };
 // Texture side of a material (closest_hit.slang:42-46,65-66,82-87): factors (the sample_texture fallbacks) and the
 // resolved (image, sampler) slots. Sampler codes: bit0 = mag filter LINEAR, bits1-2 = address mode u, bits3-4 = v.
-struct DevMeshTex {    // 64 B
+struct DevMeshTex {    // 72 B
     float base_color[4];
     float emissive_factor[3], emissive_strength;
     float roughness, metallic;
     uint32_t img_base, img_mr;
     uint32_t img_normal, img_emissive;
     uint32_t samplers;           // base | mr << 8 | normal << 16 | emissive << 24
+    uint32_t alpha_mode;         // any_hit.slang:23 (0 in every material Material::new builds, material.rs:74)
+    float alpha_cutoff;          // any_hit.slang:40
     uint32_t _pad;
 };
 struct DevTexture {    // 16 B: R8G8B8A8_UNORM, one mip level, R in the low byte (image/mod.rs:96-107)
@@ -426,6 +428,25 @@ SRD void shade_textured(const DevScene& sc, uint32_t slot, uint32_t inst, uint32
         metallic = metallic * mr.z;
     }
     pl.material_info = pack_half_2x16(roughness, metallic);
+}
+
+// any_hit.slang:11-43: true where the shader calls IgnoreHit(). Dead in the reference (OPAQUE geometry, alpha_mode forced
+// 0), so the traversal does not call it; sr_any_hit_ignores applies it to hit records (K5 parity hook).
+SRD bool any_hit_ignores(const DevScene& sc, uint32_t slot, float u, float v) {
+    const float4 s2 = sc.shade[(size_t)slot * 3 + 2];
+    const uint32_t mesh = __float_as_uint(s2.z);
+    const DevMeshTex mt = sc.mesh_tex[mesh];
+    if (mt.alpha_mode == 0u) return false;                                               // :23-25
+    float4 base_color = make_float4(mt.base_color[0], mt.base_color[1], mt.base_color[2], mt.base_color[3]);
+    if (mt.img_base != 0xFFFFFFFFu) {                                                    // sample_texture's NULL case is its fallback
+        const f3 bary = mk3(1.0f - u - v, u, v);                                         // :27-29
+        const float4* q = sc.shade_tex + (size_t)slot * 6;
+        const float4 q0 = q[0], q1 = q[1];
+        const float uv_s = (q0.x * bary.x + q0.z * bary.y) + q1.x * bary.z;              // :36-37
+        const float uv_t = (q0.y * bary.x + q0.w * bary.y) + q1.y * bary.z;
+        base_color = sample_texture(sc, mt.img_base, mt.samplers & 0xFFu, uv_s, uv_t, base_color);   // :39
+    }
+    return base_color.w < mt.alpha_cutoff;                                               // :40-42
 }
 
 template <bool TEX>

@@ -285,6 +285,12 @@ class Scene:
         check(lib().sr_shade_closest_hit(self._h, C.c_void_p(hits_t.data_ptr()), C.c_uint32(n), C.c_void_p(out.data_ptr()), self._stream()))
         return out
 
+    def any_hit_ignores(self, hits_t, n):
+        import torch
+        out = torch.empty(n, dtype=torch.int32, device=hits_t.device)
+        check(lib().sr_any_hit_ignores(self._h, C.c_void_p(hits_t.data_ptr()), C.c_uint32(n), C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
     def params(self, frame, matrices, frame_count, config=None, tile=None):
         p = abi.SrRtParams()
         p.scene = self._h
@@ -441,6 +447,23 @@ class Renderer:
     def resize(self, size):
         check(lib().sr_renderer_resize(self._h, C.c_uint32(int(size[0])), C.c_uint32(int(size[1]))))
         self.size = (int(size[0]), int(size[1]))
+
+    # Frame / resize callbacks (lib.rs:537-554). The ctypes thunks are kept alive for the renderer's lifetime.
+    _FRAME_CB = C.CFUNCTYPE(None, C.c_void_p)
+    _RESIZE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32)
+
+    def _keep(self, thunk):
+        self.__dict__.setdefault("_thunks", []).append(thunk)
+        return thunk
+
+    def add_start_of_frame_callback(self, fn):
+        check(lib().sr_renderer_add_start_of_frame_callback(self._h, self._keep(self._FRAME_CB(lambda _u: fn())), None))
+
+    def add_end_of_frame_callback(self, fn):
+        check(lib().sr_renderer_add_end_of_frame_callback(self._h, self._keep(self._FRAME_CB(lambda _u: fn())), None))
+
+    def add_resize_callback(self, fn):
+        check(lib().sr_renderer_add_resize_callback(self._h, self._keep(self._RESIZE_CB(lambda _u, w, h: fn((w, h)))), None))
 
     def load_mesh(self, key, vertices, indices, material):
         v = np.ascontiguousarray(vertices, dtype=abi.VERTEX)

@@ -217,6 +217,40 @@ def test_textured_closest_hit_payloads(rt, oracle):
     assert len(np.unique(pl["material_info"][hit])) > 500
 
 
+def test_any_hit_alpha_test_equals_oracle(rt, oracle):
+    """K5, any_hit.slang:11-43, on both sides. The reference never runs the shader (OPAQUE geometry, blas.rs:276; alpha_mode
+    forced 0, material.rs:74), so the materials are given MASK modes by hand: textured with a varying alpha channel, an RGB
+    image (alpha widened to 0, utils.rs:27-43), untextured (the base-colour factor's alpha is the fallback), and
+    alpha_mode == 0 (returns before sampling)."""
+    desc = small_atrium()
+    img = desc.images[0].copy()                                  # marble, RGBA: alpha becomes a diagonal ramp with noise
+    hh, ww = img.shape[:2]
+    jj, ii = np.meshgrid(np.arange(ww), np.arange(hh))
+    img[..., 3] = ((jj * 3 + ii * 5 + (img[..., 0].astype(np.int64) % 7) * 9) % 256).astype(np.uint8)
+    desc.images[0] = img
+    for k, m in enumerate(desc.meshes):
+        m.material = m.material.copy()
+        m.material["alpha_mode"] = [1, 2, 0, 1][k % 4]           # MASK / BLEND are both "!= 0" to the shader
+        m.material["alpha_cutoff"] = [0.5, 0.25, 0.9, 1.5, 0.0][k % 5]
+        if k % 3 == 1:
+            bc = m.material["base_color_value"].copy(); bc[..., 3] = 0.3; m.material["base_color_value"] = bc
+    osc = oracle.OracleScene().load(desc)
+    gsc = rt.Scene(0).load(desc)
+    rays = np.concatenate([camera_rays(oracle, desc, 200, 120), random_rays(30000, 35, box=((-8, 0.1, -17), (8, 6.5, 17)))])
+    hits_t = gsc.trace_closest(rt.rays_to_device(rays), len(rays))
+    hits = rt.hits_from_device(hits_t)
+    assert_bits_equal(osc.trace_closest(rays), hits, "SrHit")
+    got = gsc.any_hit_ignores(hits_t, len(rays)).cpu().numpy().view(np.uint32)
+    want = osc.any_hit_ignores(hits)
+    assert np.array_equal(want, got)
+    hit = hits["tri"] != 0xFFFFFFFF
+    assert 0.1 < got[hit].mean() < 0.9 and not got[~hit].any()      # both outcomes occur; misses are never "ignored"
+    # the traversal itself stays opaque: any-hit queries report the same occlusion as before the materials changed
+    plain = rt.Scene(0).load(small_atrium())
+    rd = rt.rays_to_device(rays)
+    assert np.array_equal(plain.trace_any(rd, len(rays)).cpu().numpy(), gsc.trace_any(rd, len(rays)).cpu().numpy())
+
+
 def test_texture_error_behaviour(rt):
     from sunray_amd._lib import SunrayError
     g = rt.Scene(0)
@@ -394,6 +428,30 @@ def test_error_behaviour(rt, blue_noise):
     with pytest.raises(SunrayError) as e:
         g.add_mesh(4, v, i, tex)
     assert e.value.code == -1 and "never added" in e.value.description   # dangling texture slot
+    # non-finite input never reaches the builders (their quantiser would be undefined on it)
+    bad = v.copy(); bad["position"][2, 1] = np.nan
+    with pytest.raises(SunrayError) as e:
+        g.add_mesh(5, bad, i, abi.material())
+    assert "non-finite position" in e.value.description
+    nan_xf = np.array(abi.IDENTITY_TRANSFORM, dtype=np.float32).copy(); nan_xf.reshape(-1)[7] = np.inf
+    with pytest.raises(SunrayError) as e:
+        g.set_instances([(1, [nan_xf])])
+    assert "non-finite" in e.value.description
+    import ctypes as C
+    from sunray_amd._lib import lib, check
+    keys, counts = (C.c_uint64 * 1)(1), (C.c_uint32 * 1)(2)
+    with pytest.raises(SunrayError) as e:      # instances announced, no transforms
+        check(lib().sr_scene_set_instances(g._h, keys, counts, C.c_uint32(1), None))
+    assert "transforms is null" in e.value.description
+    counts[0] = 0xFFFFFFFF                     # 2^32 - 1 instances of a 2-triangle mesh: the 32-bit triangle offset would wrap
+    with pytest.raises(SunrayError) as e:
+        check(lib().sr_scene_set_instances(g._h, keys, counts, C.c_uint32(1), C.c_void_p(8)))
+    assert e.value.code == -5 and "2^28 triangles" in e.value.description
+    g.set_instances([(1, [abi.IDENTITY_TRANSFORM])])          # the scene is still usable
+    rays = rt.rays_to_device(random_rays(64, 1))
+    with pytest.raises(SunrayError) as e:
+        check(lib().sr_trace_closest(g._h, C.c_void_p(rays.data_ptr()), C.c_uint32(0x90000000), C.c_void_p(rays.data_ptr()), None))
+    assert "2^31 rays" in e.value.description
 
 
 # ---- post-RT compute chain --------------------------------------------------------
@@ -536,6 +594,71 @@ def test_renderer_resize_and_instance_change(rt, oracle):
     hip = C.CDLL("libamdhip64.so")
     assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), outp, C.c_size_t(got.nbytes), C.c_int(2)) == 0
     assert_bits_equal(of.output, got, "output after resize + moved instances")
+    r.close()
+
+
+def test_renderer_frame_and_resize_callbacks(rt):
+    """add_start_of_frame_callback / add_end_of_frame_callback / add_resize_callback (lib.rs:537-594): a start-of-frame
+    callback runs once at the start of the next render; an end-of-frame callback only once that frame has completed on
+    the GPU, drained at the start of a later render; resize callbacks are persistent and see every resize call."""
+    desc = scenes.cornell_box()
+    r = rt.Renderer((64, 48))
+    for m in desc.meshes:
+        r.load_mesh(m.key, m.vertices, m.indices, m.material)
+    cam = (desc.camera_pos, desc.camera_target, desc.fov_y)
+    log = []
+    r.add_start_of_frame_callback(lambda: log.append(("start", r.relative_frame_count)))
+    r.add_end_of_frame_callback(lambda: log.append(("end", r.relative_frame_count)))
+    r.add_resize_callback(lambda size: log.append(("resize", size)))
+    assert log == []
+    f1 = r.render(cam, desc.instances)                       # frame 1: the start callback fires before any frame work
+    assert log == [("start", 0)]
+    r.wait_frame(f1)
+    assert log == [("start", 0)]                             # completion alone does not run it: the reference drains in render()
+    f2 = r.render(cam, desc.instances)
+    assert log == [("start", 0), ("end", 1)]                 # frame 1 is complete -> drained at the start of frame 2, once
+    r.wait_frame(f2)
+    r.wait_frame(r.render(cam, desc.instances))
+    assert log == [("start", 0), ("end", 1)]
+    # a callback may schedule the next one (tagged for a later frame)
+    r.add_start_of_frame_callback(lambda: r.add_start_of_frame_callback(lambda: log.append(("chained", r.relative_frame_count))))
+    r.wait_frame(r.render(cam, desc.instances)); assert ("chained", 4) not in log
+    r.wait_frame(r.render(cam, desc.instances)); assert log[-1] == ("chained", 4)
+    r.resize((64, 48)); r.resize((80, 56))
+    assert log[-2:] == [("resize", (64, 48)), ("resize", (80, 56))] and r.relative_frame_count == 0
+    with pytest.raises(rt.SunrayError):
+        from sunray_amd._lib import lib, check
+        check(lib().sr_renderer_add_resize_callback(r._h, None, None))
+    r.close()
+
+
+def test_load_unload_cycles_do_not_leak_hbm(rt, tmp_path):
+    """Renderer::unload_scene frees every asset of the group — BLASes AND images (ResourceManager::remove,
+    resource_manager.rs:459-472): loading and unloading a textured scene repeatedly leaves the free HBM where it was."""
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import gltf_util
+    desc = scenes.atrium(columns_per_side=4, col_segments=16, col_rings=4, floor_div=8, tex=512, n_lamps=6)   # ~6 MB of texels
+    path = str(tmp_path / "atrium512.glb")
+    gltf_util.scene_to_gltf(desc, path)
+    r = rt.Renderer((64, 48))
+    cam = (desc.camera_pos, desc.camera_target, desc.fov_y)
+    free = []
+    for cycle in range(6):
+        group, inst = r.load_gltf(path)
+        r.wait_frame(r.render(cam, inst))
+        r.unload_scene(group)
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info()[0])
+    assert group == 5
+    assert abs(free[-1] - free[1]) < (1 << 20), free          # after the first cycle (allocator warm-up) nothing accumulates
+    # a freed image slot is not usable until re-added
+    from sunray_amd._lib import lib, check
+    import ctypes as C
+    sc = C.c_void_p()
+    check(lib().sr_renderer_get(r._h, C.byref(sc), None, None, None))
+    with pytest.raises(rt.SunrayError):
+        check(lib().sr_scene_remove_image(sc, C.c_uint32(0)))
     r.close()
 
 
@@ -771,6 +894,29 @@ def test_device_lbvh_fast_build(rt, oracle, blue_noise, scene_fn, box):
     assert_bits_equal(osc.trace_closest(rays), rt.hits_from_device(gsc.trace_closest(rays_t, len(rays))), "SrHit (LBVH + update)")
     nodes, tris = gsc.read_bvh()
     _check_bvh(nodes, tris, st.max_depth, st.max_stack, stack_limit=47)
+
+
+def test_device_radix_tree_fast_build_switch(rt, oracle, monkeypatch):
+    """SR_FAST_BUILD=lbvh (read at sr_scene_create) selects Karras' binary radix tree instead of PLOC for the device fast
+    build: a different, equally valid tree — same structural checks, same hits as the oracle."""
+    from test_host_abi import _check_bvh
+    desc = scenes.torus_knot()
+    osc = oracle.OracleScene().load(desc)
+    plain = rt.Scene(0).load(desc)
+    plain.force_next_op(abi.OP_FAST_BUILD); plain.set_instances(desc.instances)
+    monkeypatch.setenv("SR_FAST_BUILD", "lbvh")
+    gsc = rt.Scene(0).load(desc)
+    monkeypatch.delenv("SR_FAST_BUILD")
+    gsc.force_next_op(abi.OP_FAST_BUILD); gsc.set_instances(desc.instances)
+    st = gsc.bvh_stats()
+    assert gsc.as_state()[1] == abi.OP_FAST_BUILD and st.sah_cost == 0.0
+    nodes, tris = gsc.read_bvh()
+    _check_bvh(nodes, tris, st.max_depth, st.max_stack, stack_limit=47)
+    assert (st.n_nodes, st.max_depth) != (plain.bvh_stats().n_nodes, plain.bvh_stats().max_depth)     # really another topology
+    rays = np.concatenate([camera_rays(oracle, desc, 160, 90), random_rays(20000, 6, box=((-4, 0, -4), (4, 5, 4)))])
+    rays_t = rt.rays_to_device(rays)
+    assert_bits_equal(osc.trace_closest(rays), rt.hits_from_device(gsc.trace_closest(rays_t, len(rays))), "SrHit (radix tree)")
+    assert np.array_equal(osc.trace_any(rays), gsc.trace_any(rays_t, len(rays)).cpu().numpy().view(np.uint32))
 
 
 def test_4k_frame_1m_triangles(rt, oracle, blue_noise):

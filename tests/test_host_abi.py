@@ -74,6 +74,16 @@ def test_material_and_emissive_derivation_match_oracle(oracle):
     assert np.allclose(et[1]["v2"], [-0.3, 1.99, 0.3, 0.0])
     # not emissive when every component of factor*strength is <= 0 (lib.rs:907)
     assert len(rt.emissive_triangles_from_mesh(v, i, abi.material(emissive_factor=(1, 1, 1), emissive_strength=0.0))) == 0
+    # count query (out = NULL, cap = 0) is fine; out = NULL with cap > 0 is a caller bug, not a silent no-op
+    from sunray_amd._lib import lib, SunrayError, check
+    vv, ii, mm = np.ascontiguousarray(v, dtype=abi.VERTEX), np.ascontiguousarray(i, dtype=np.uint32), np.ascontiguousarray(m, dtype=abi.MATERIAL)
+    n = C.c_uint32()
+    args = (vv.ctypes.data_as(C.c_void_p), C.c_uint32(len(vv)), ii.ctypes.data_as(C.c_void_p), C.c_uint32(len(ii)), mm.ctypes.data_as(C.c_void_p))
+    check(lib().sr_emissive_triangles_from_mesh(*args, None, C.c_uint32(0), C.byref(n)))
+    assert n.value == 2
+    with pytest.raises(SunrayError) as e:
+        check(lib().sr_emissive_triangles_from_mesh(*args, None, C.c_uint32(4), C.byref(n)))
+    assert e.value.code == -1 and "cap > 0" in e.value.description
 
 
 def _world_tris(desc):
