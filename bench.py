@@ -262,10 +262,12 @@ def main():
     pipe = sd.GatherPipeline(part, rank, "cpu" if rehearsal else device) if world > 1 else None
 
     state = {"prev": None, "frame": 0, "last": frame}
-    # Two frames in flight per GPU (RIS of frame f+1 overlaps the draining final pass of frame f): a rank's share of a frame
-    # is about one round of waves, i.e. latency-bound on its own. On by default for N > 1; N = 1 runs the passes back to
-    # back so that the per-launch durations behind `roofline` are those of undisturbed kernels.
-    pipelined = os.environ.get("SUNRAY_BENCH_PIPELINE", "1" if world > 1 else "0") == "1"
+    # Two frames in flight per GPU, as the reference renders (MAX_FRAMES_IN_FLIGHT = 2, src/lib.rs:71): raytracing_ris of frame
+    # f+1 runs on its own stream while raytracing_final of frame f drains, so the tail of one launch is filled by the head of
+    # the next (bit-identical to sequential execution: same CRC). Worth 5-6 % at N = 1 and more on a strip (N > 1: a rank's
+    # share is about one round of waves). Per-launch durations then include the time a kernel shares the GPU with its
+    # neighbour; SUNRAY_BENCH_PIPELINE=0 runs the passes back to back (undisturbed kernel durations).
+    pipelined = os.environ.get("SUNRAY_BENCH_PIPELINE", "1") == "1"
     fpipe = sd.FramePipeline(frame, rt.DeviceFrame(W, H, blue_noise, device=device)) if pipelined else None
 
     def submit_gather(fr):
