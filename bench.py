@@ -87,6 +87,8 @@ def live_pmc(argv_tail, timeout_s=150):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return {"error": "rocprofv3 not found"}
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return {"error": "this process itself runs under a profiler (no nested counter passes)"}
     work = tempfile.mkdtemp(prefix="sunray_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     out = {"kernels": {}, "passes": []}
@@ -396,8 +398,9 @@ def main():
         bounds_dom = bounds_of(dom, avg_ms, req)
         binding_name = max(bounds_dom, key=lambda n: bounds_dom[n]["frac"])
         binding = bounds_dom[binding_name]
-        pmc_note = ("live: %d rocprofv3 --pmc passes of this workload run by this process before the timed region (%.0f s), HEAD %s"
-                    % (len(pmc["passes"]), pmc["seconds"], git_head())) if pmc and "error" not in pmc else \
+        head = git_head()
+        pmc_note = ("live: %d rocprofv3 --pmc passes of this workload run by this process before the timed region (%.0f s)%s"
+                    % (len(pmc["passes"]), pmc["seconds"], ", HEAD " + head if head else "")) if pmc and "error" not in pmc else \
                    ("not measured: " + (pmc["error"] if pmc else "N > 1 or --no-pmc"))
         out = {
             "metric": "Mray/s (closest-hit + any-hit queries issued per second), 1920x1080, 1 spp, 1M-triangle scene",
@@ -446,7 +449,9 @@ def main():
                 "tris_per_ray": ck.tris_tested / nq,
                 "other_pass": {"kernel": KERNEL_OF[other], "avg_launch_ms": other_ms,
                                "bounds": bounds_of(other, other_ms, requested_bytes(per_kind[other], n_own_pixels, other))},
-                "note": "three physical rooflines per pass, `bound` = the one with the largest fraction. The passes gather 64-byte BVH nodes and "
+                "launches_overlap": bool(pipelined),
+                "note": "three physical rooflines per pass, `bound` = the one with the largest fraction. With two frames in flight a launch "
+                        "shares the GPU with its neighbour (avg_launch_ms is its wall time, the counters are per launch). The passes gather 64-byte BVH nodes and "
                         "48-byte triangles that live in L2 / Infinity Cache (16.5 MB + 48 MB), so HBM is not the binding roof; none of the three "
                         "is saturated: a node step waits for the slowest of its lanes' dependent fetches (DESIGN.md section 5)",
             },
