@@ -629,10 +629,9 @@ struct GltfLoader {
                 if (bi < 0 || (size_t)bi >= buffers.size() || off + len > buffers[bi].size()) return fail("image bufferView exceeds its buffer");
                 bytes.assign(buffers[bi].begin() + off, buffers[bi].begin() + off + len);
             }
-            if (bytes.size() >= 3 && bytes[0] == 0xFF && bytes[1] == 0xD8) return fail("JPEG images are not supported by this loader (PNG only)", SR_ERR_UNSUPPORTED);
             DecodedImage im;
             std::string ierr;
-            if (!decode_png(bytes.data(), bytes.size(), im, ierr)) return fail(ierr, SR_ERR_UNSUPPORTED);
+            if (!srh::decode_image(bytes.data(), bytes.size(), im.w, im.h, im.channels, im.pixels, ierr)) return fail(ierr, SR_ERR_UNSUPPORTED);
             out.images.push_back(std::move(im));
         }
         for (const auto& t : out.textures) {
@@ -659,7 +658,31 @@ struct GltfLoader {
 
 struct SrGltf { srh::GltfScene scene; };
 
+namespace srh {
+bool decode_image(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height, uint32_t& channels, std::vector<uint8_t>& pixels, std::string& err) {
+    if (n >= 3 && data[0] == 0xFF && data[1] == 0xD8) return decode_jpeg(data, n, width, height, channels, pixels, err);   // gltf::import sniffs the content too
+    DecodedImage im;
+    if (!decode_png(data, n, im, err)) return false;
+    width = im.w; height = im.h; channels = im.channels; pixels.swap(im.pixels);
+    return true;
+}
+}  // namespace srh
+
 extern "C" {
+
+// The image decoder of the glTF loader on its own (PNG 8-bit, baseline JPEG): extent and channel count, and — when `pixels`
+// is non-null and `cap` is large enough — the w * h * channels bytes Image::new_from_data would be handed.
+int sr_decode_image(const uint8_t* data, size_t n, uint32_t* width, uint32_t* height, uint32_t* channels, uint8_t* pixels, size_t cap) {
+    if (!data || !width || !height || !channels) return srh::set_error(SR_ERR_INVALID_ARG, "sr_decode_image: null argument");
+    std::vector<uint8_t> px;
+    std::string err;
+    if (!srh::decode_image(data, n, *width, *height, *channels, px, err)) return srh::set_error(SR_ERR_UNSUPPORTED, err);
+    if (pixels) {
+        if (cap < px.size()) return srh::set_error(SR_ERR_INVALID_ARG, "sr_decode_image: output too small");
+        memcpy(pixels, px.data(), px.size());
+    }
+    return SR_OK;
+}
 
 // Gltf::new + create_default_scene + the CPU side of Scene::load_into_gpu
 int sr_gltf_open(const char* path, SrGltf** out) {

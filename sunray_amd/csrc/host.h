@@ -88,6 +88,11 @@ void as_state_mark_built(SrAsState& s, uint32_t completed_op);
 // deepest level first; level_offsets has n_levels + 1 entries.
 void tree_levels(const std::vector<uint32_t>& nodes, std::vector<uint32_t>& level_nodes, std::vector<uint32_t>& level_offsets);
 
+// Baseline JPEG -> 8-bit pixels, 1 (greyscale) or 3 (RGB) channels (jpeg_decode.cpp)
+bool decode_jpeg(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height, uint32_t& channels, std::vector<uint8_t>& pixels, std::string& err);
+// PNG / JPEG by content, as the loader decodes glTF images (gltf_load.cpp)
+bool decode_image(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height, uint32_t& channels, std::vector<uint8_t>& pixels, std::string& err);
+
 // the one thread-local error slot of the library (api.cpp); returns `code`
 int set_error(int code, const std::string& msg);
 }  // namespace srh

@@ -37,6 +37,16 @@ def material_new(base_color, metallic, roughness, emissive_factor, emissive_stre
     return m
 
 
+def decode_image(data):
+    """The glTF loader's image decoder on its own (8-bit PNG, baseline JPEG) -> (h, w, channels) uint8."""
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+    w, h, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    check(lib().sr_decode_image(buf, C.c_size_t(len(data)), C.byref(w), C.byref(h), C.byref(c), None, C.c_size_t(0)))
+    out = np.zeros((h.value, w.value, c.value), dtype=np.uint8)
+    check(lib().sr_decode_image(buf, C.c_size_t(len(data)), C.byref(w), C.byref(h), C.byref(c), _p(out), C.c_size_t(out.size)))
+    return out
+
+
 def emissive_triangles_from_mesh(vertices, indices, material):
     v = np.ascontiguousarray(vertices, dtype=abi.VERTEX)
     i = np.ascontiguousarray(indices, dtype=np.uint32)

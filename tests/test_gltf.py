@@ -205,6 +205,53 @@ def test_png_decoder_against_reference_decoder(tmp_path):
     assert (rt.gltf_parse(str(tmp_path / "p26.glb"))["images"][0][..., 0] == idx4 * 17).all()
 
 
+def test_jpeg_decoder_against_libjpeg(tmp_path):
+    """Baseline JPEG textures (what `gltf::import` decodes through the image crate): greyscale, 4:4:4 / 4:2:2 / 4:2:0
+    chroma, optimised Huffman tables, restart intervals, odd extents — against Pillow's libjpeg within the margin JPEG leaves
+    to the decoder (inverse-DCT rounding: a few units; the chroma filters are the IJG ones on both sides). PARITY UNPINNED
+    with respect to the reference's own decoder (zune-jpeg, not under /root/reference). Progressive files are refused."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    yy, xx = np.mgrid[0:97, 0:131]
+    img = np.stack([128 + 100 * np.sin(xx / 17.0) * np.cos(yy / 11.0), 128 + 90 * np.cos(xx / 23.0 + yy / 31.0), 60 + xx + yy * 0.5], -1).clip(0, 255).astype(np.uint8)
+    noise = np.random.default_rng(3).integers(0, 256, size=(40, 56, 3), dtype=np.uint8)
+
+    def enc(a, **kw):
+        b = io.BytesIO()
+        PIL.fromarray(a).save(b, "JPEG", **kw)
+        return b.getvalue()
+    cases = [(img, dict(quality=90, subsampling=0)), (img, dict(quality=85, subsampling=1)), (img, dict(quality=75, subsampling=2)),
+             (img, dict(quality=95, subsampling=2, optimize=True)), (img, dict(quality=80, subsampling=2, restart_marker_blocks=3)),
+             (img[..., 0], dict(quality=80)), (noise, dict(quality=60, subsampling=2)), (img[:9, :17], dict(quality=90, subsampling=2)),
+             (img[:8, :8], dict(quality=90, subsampling=0))]
+    for k, (a, kw) in enumerate(cases):
+        data = enc(a, **kw)
+        got = rt.decode_image(data)
+        ref = np.asarray(PIL.open(io.BytesIO(data)))
+        ref = ref[..., None] if ref.ndim == 2 else ref
+        assert got.shape == ref.shape == (a.shape[0], a.shape[1], 1 if a.ndim == 2 else 3), k
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert d.max() <= 4 and d.mean() < 0.2, (k, d.max(), d.mean())
+    # through the glTF loader: a JPEG-textured triangle parses and carries the decoded RGB image
+    data = enc(img, quality=85, subsampling=2)
+    b = gltf_util.GltfBuilder()
+    b.doc["images"].append({"bufferView": b.view(data), "mimeType": "image/jpeg"})
+    b.add("textures", {"source": 0})
+    prim = _tri_mesh(b, 1, 0)
+    b.add("meshes", {"primitives": [prim]})
+    b.add("scenes", {"nodes": [b.add("nodes", {"mesh": 0})]})
+    path = str(tmp_path / "jpeg.glb")
+    b.write_glb(path)
+    parsed = rt.gltf_parse(path)["images"][0]
+    assert parsed.shape == (97, 131, 3) and (parsed == rt.decode_image(data)).all()
+    with pytest.raises(SunrayError) as e:
+        rt.decode_image(enc(img, quality=80, progressive=True))
+    assert e.value.code == -5 and "progressive" in e.value.description
+    with pytest.raises(SunrayError):
+        rt.decode_image(data[:len(data) // 2])                    # truncated entropy-coded data / missing EOI must not crash
+    assert (rt.decode_image(gltf_util.encode_png(noise)) == noise).all()      # the same entry point decodes PNG by content
+
+
 def test_loader_errors(tmp_path):
     def expect(mutate, text, code=-1):
         b = gltf_util.GltfBuilder()
