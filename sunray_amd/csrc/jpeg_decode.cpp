@@ -265,15 +265,16 @@ bool decode_jpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, 
                                 const int s = decode_symbol(br, dc[c->td], ok);
                                 if (!ok || s > 11) { ok = false; break; }
                                 c->pred += extend(br.bits(s), s);
-                                coef[0] = c->pred * qt[c->tq][0];
+                                if (c->pred < -32768 || c->pred > 32767) { ok = false; break; }     // an 8-bit image's DC fits 12 bits: corrupt data
+                                coef[0] = c->pred * (int)qt[c->tq][0];
                                 for (int k = 1; k < 64;) {
                                     const int rs = decode_symbol(br, ac[c->ta], ok);
                                     if (!ok) break;
                                     const int r = rs >> 4, sz = rs & 15;
                                     if (sz == 0) { if (r == 15) { k += 16; continue; } break; }      // ZRL / EOB
                                     k += r;
-                                    if (k > 63) { ok = false; break; }
-                                    coef[kZigzag[k]] = extend(br.bits(sz), sz) * qt[c->tq][kZigzag[k]];
+                                    if (k > 63 || sz > 11) { ok = false; break; }                     // AC categories of 8-bit data are <= 10
+                                    coef[kZigzag[k]] = extend(br.bits(sz), sz) * (int)qt[c->tq][kZigzag[k]];
                                     k++;
                                 }
                                 if (!ok) break;
