@@ -83,60 +83,67 @@ __global__ __launch_bounds__(256) void temporal_kernel(SrPostParams p) {
 // values in the same tap order as the straightforward form, so the output bits do not change.
 constexpr int kPatch = kTile + 4;             // 20
 constexpr int kPatchN = kPatch * kPatch;      // 400
+// LDS image of the patch: one 48-byte record per lattice point = three float4 (illumination.xyz, luminance |
+// diffuse.xyz, depth | normal.xyz, inside-the-image flag), so a tap costs three ds_read_b128 instead of twelve ds_read_b32
+// (the LDS pipe was a third of the pass). A patch row is padded from 60 to 64 float4: with a row stride that is a multiple of
+// 16 slots the 48-byte-strided reads of the two half-rows a ds_read_b128 lane group covers fall on complementary slots
+// (3 lx mod 16 over lx = 0-3, 12-15 and over lx = 4-11): conflict-free.
+constexpr int kRowSlots = 64;                 // float4 per patch row (20 records x 3, padded)
 __global__ __launch_bounds__(256) void denoise_kernel(SrPostParams p, const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int step_width) {
-    __shared__ float t_ix[kPatchN], t_iy[kPatchN], t_iz[kPatchN], t_lu[kPatchN];    // illumination + luminance
-    __shared__ float t_dx[kPatchN], t_dy[kPatchN], t_dz[kPatchN];                   // diffuse
-    __shared__ float t_nx[kPatchN], t_ny[kPatchN], t_nz[kPatchN], t_de[kPatchN];    // normal, depth
-    __shared__ uint32_t t_ok[kPatchN];                                              // inside the image
+    __shared__ float4 patch[kPatch * kRowSlots];                                    // 20 KB
     const int W = (int)p.width, H = (int)p.height, s = step_width;
     const int rx = (int)blockIdx.x % s, ry = (int)blockIdx.y % s;                   // residue class = which lattice
     const int l0x = ((int)blockIdx.x / s) * kTile, l0y = ((int)blockIdx.y / s) * kTile;   // tile origin in lattice coordinates
     for (int i = (int)threadIdx.x; i < kPatchN; i += 256) {
-        const int sx = rx + s * (l0x - 2 + i % kPatch), sy = ry + s * (l0y - 2 + i / kPatch);
+        const int px_ = i % kPatch, py_ = i / kPatch;
+        const int sx = rx + s * (l0x - 2 + px_), sy = ry + s * (l0y - 2 + py_);
         const bool ok = sx >= 0 && sy >= 0 && sx < W && sy < H;
-        t_ok[i] = ok ? 1u : 0u;
-        if (!ok) continue;
+        float4* rec = patch + py_ * kRowSlots + px_ * 3;
+        if (!ok) { rec[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); continue; }
         const size_t j = (size_t)sy * W + sx;
         const f3 sample_color = unpack_b10g11r11(src[j]);
         const uint32_t sn = p.normal_img[j];
         const f3 sample_diffuse = unpack_b10g11r11(p.diffuse_img[j]);
         const f3 sample_illum = vdiv(sample_color, vmax(sample_diffuse, splat(0.001f)));
-        t_ix[i] = sample_illum.x; t_iy[i] = sample_illum.y; t_iz[i] = sample_illum.z;
-        t_lu[i] = luminance(sample_illum);
-        t_dx[i] = sample_diffuse.x; t_dy[i] = sample_diffuse.y; t_dz[i] = sample_diffuse.z;
-        t_nx[i] = unsnorm8(sn); t_ny[i] = unsnorm8(sn >> 8); t_nz[i] = unsnorm8(sn >> 16);
-        t_de[i] = f16_bits_to_f32(p.depth_img[j]);
+        rec[0] = make_float4(sample_illum.x, sample_illum.y, sample_illum.z, luminance(sample_illum));
+        rec[1] = make_float4(sample_diffuse.x, sample_diffuse.y, sample_diffuse.z, f16_bits_to_f32(p.depth_img[j]));
+        rec[2] = make_float4(unsnorm8(sn), unsnorm8(sn >> 8), unsnorm8(sn >> 16), 1.0f);
     }
     __syncthreads();
     const int lx = (int)threadIdx.x & 15, ly = (int)threadIdx.x >> 4;
     const int x = rx + s * (l0x + lx), y = ry + s * (l0y + ly);
     if (x >= W || y >= H) return;
     const size_t i = (size_t)y * W + x;
-    const int tc = (ly + 2) * kPatch + (lx + 2);
+    const float4* centre = patch + (ly + 2) * kRowSlots + (lx + 2) * 3;
     const f3 center_color = unpack_b10g11r11(src[i]);
-    const float center_depth = t_de[tc];
+    const float4 c1 = centre[1];
+    const float center_depth = c1.w;
     if (center_depth >= 10000.0f) { dst[i] = pack_b10g11r11(center_color.x, center_color.y, center_color.z); return; }
-    const f3 center_normal = mk3(t_nx[tc], t_ny[tc], t_nz[tc]);
+    const float4 c2 = centre[2];
+    const f3 center_normal = mk3(c2.x, c2.y, c2.z);
     const float center_roughness = unsnorm8(p.normal_img[i] >> 24);
-    const f3 center_diffuse = mk3(t_dx[tc], t_dy[tc], t_dz[tc]);
+    const f3 center_diffuse = mk3(c1.x, c1.y, c1.z);
     if (center_roughness < 0.1f) { dst[i] = pack_b10g11r11(center_color.x, center_color.y, center_color.z); return; }
-    const f3 center_illum = mk3(t_ix[tc], t_iy[tc], t_iz[tc]);
+    const float4 c0 = centre[0];
+    const f3 center_illum = mk3(c0.x, c0.y, c0.z);
     const float kernel[5] = {1.0f / 16.0f, 4.0f / 16.0f, 6.0f / 16.0f, 4.0f / 16.0f, 1.0f / 16.0f};
     const float center_weight = kernel[2] * kernel[2];
     f3 sum_color = center_illum * center_weight;
     float sum_weight = center_weight;
-    const float center_luma = t_lu[tc];
+    const float center_luma = c0.w;
 #pragma unroll
     for (int dy = -2; dy <= 2; ++dy) {
 #pragma unroll
         for (int dx = -2; dx <= 2; ++dx) {
-            const int t = tc + dy * kPatch + dx;
-            if (!t_ok[t]) continue;
-            const f3 sample_illum = mk3(t_ix[t], t_iy[t], t_iz[t]);
-            const f3 sample_diffuse = mk3(t_dx[t], t_dy[t], t_dz[t]);
-            const f3 sample_normal = mk3(t_nx[t], t_ny[t], t_nz[t]);
-            const float sample_depth = t_de[t];
-            const float sample_luma = t_lu[t];
+            const float4* rec = centre + dy * kRowSlots + dx * 3;
+            const float4 r2 = rec[2];
+            if (r2.w == 0.0f) continue;                                             // outside the image (denoise.slang:83-86)
+            const float4 r0 = rec[0], r1 = rec[1];
+            const f3 sample_illum = mk3(r0.x, r0.y, r0.z);
+            const f3 sample_diffuse = mk3(r1.x, r1.y, r1.z);
+            const f3 sample_normal = mk3(r2.x, r2.y, r2.z);
+            const float sample_depth = r1.w;
+            const float sample_luma = r0.w;
             const float diffuse_diff = len3(center_diffuse - sample_diffuse);
             const float luma_diff = fabsf(center_luma - sample_luma);
             const float luma_sigma = fmaxf(center_luma, sample_luma) * 0.4f + 0.01f;
