@@ -1,4 +1,5 @@
-// Baseline JPEG (ITU-T T.81 / ISO 10918-1, sequential DCT, Huffman, 8-bit) -> 8-bit pixels for the glTF loader.
+// JPEG (ITU-T T.81 / ISO 10918-1: baseline, extended sequential and progressive DCT, Huffman-coded, 8-bit) -> 8-bit pixels for the
+// glTF loader.
 //
 // The reference gets its textures from `gltf::import` (gltf/mod.rs:57-67), which decodes JPEG through the `image` crate
 // (0.25: zune-jpeg) into R8 (greyscale) or R8G8B8 — formats Image::new_from_data accepts (image/mod.rs:98-104). The
@@ -7,7 +8,7 @@
 // units: PARITY UNPINNED for JPEG texels. This one is the standard's own definition: dequantise, the separable
 // 8x8 inverse DCT of Annex A.3.3 evaluated in double precision, level shift + round to nearest + clamp, the IJG library's
 // triangle filters for 2:1 subsampled chroma (replication for other ratios), JFIF YCbCr -> RGB. tests/test_gltf.py checks it against libjpeg (Pillow) within that margin.
-// Progressive (SOF2), arithmetic-coded, lossless, 12-bit and 4-component (CMYK) files are refused.
+// Arithmetic-coded, lossless, hierarchical, 12-bit and 4-component (CMYK) files are refused.
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -78,7 +79,8 @@ int extend(int v, int s) { return (s && v < (1 << (s - 1))) ? v - (1 << s) + 1 :
 struct Component {
     int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0;
     int bw = 0, bh = 0;                 // blocks per row / column of the plane (padded to whole MCUs)
-    std::vector<uint8_t> plane;         // bw*8 x bh*8 samples
+    std::vector<int16_t> coef;          // bw*bh blocks x 64 quantised coefficients in natural order (scans accumulate here)
+    std::vector<uint8_t> plane;         // bw*8 x bh*8 samples, after the inverse DCT
 };
 
 struct IdctTable {
@@ -163,7 +165,7 @@ bool decode_jpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, 
     Huffman dc[4], ac[4];
     std::vector<Component> comps;
     int hmax = 1, vmax = 1, restart_interval = 0, adobe_transform = -1;
-    bool have_frame = false, have_scan = false;
+    bool have_frame = false, have_scan = false, progressive = false;
     size_t pos = 2;
     while (pos + 4 <= n) {
         if (d[pos] != 0xFF) { err = "image: JPEG marker expected"; return false; }
@@ -197,7 +199,8 @@ bool decode_jpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, 
                 (tc ? ac[th] : dc[th]).build(seg + i + 1, seg + i + 17);
                 i += 17 + (size_t)total;
             }
-        } else if (m == 0xC0 || m == 0xC1) {                           // SOF0 baseline / SOF1 extended sequential (Huffman)
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {              // SOF0 baseline / SOF1 extended sequential / SOF2 progressive (Huffman)
+            progressive = m == 0xC2;
             if (have_frame) { err = "image: JPEG with several frames"; return false; }
             if (sl < 6 || seg[0] != 8) { err = "image: only 8-bit JPEG samples are supported"; return false; }
             height = be16(seg + 1); width = be16(seg + 3);
@@ -214,10 +217,11 @@ bool decode_jpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, 
             const int mcux = (int)((width + 8u * hmax - 1) / (8u * hmax)), mcuy = (int)((height + 8u * vmax - 1) / (8u * vmax));
             for (auto& c : comps) {
                 c.bw = mcux * c.h; c.bh = mcuy * c.v;
-                c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 128);
+                if ((uint64_t)c.bw * c.bh > (1u << 24)) { err = "image: JPEG too large"; return false; }
+                c.coef.assign((size_t)c.bw * c.bh * 64, 0);
             }
             have_frame = true;
-        } else if (m == 0xC2) { err = "image: progressive JPEG is not supported (baseline only)"; return false; }
+        }
         else if (m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) { err = "image: lossless / arithmetic-coded / hierarchical JPEG is not supported"; return false; }
         else if (m == 0xDD) { if (sl >= 2) restart_interval = be16(seg); }
         else if (m == 0xEE) { if (sl >= 12 && !memcmp(seg, "Adobe", 5)) adobe_transform = seg[11]; }
@@ -226,13 +230,17 @@ bool decode_jpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, 
             if (sl < 1) { err = "image: truncated JPEG scan header"; return false; }
             const int ns = seg[0];
             if (ns < 1 || ns > (int)comps.size() || sl < 1 + 2u * ns + 3u) { err = "image: bad JPEG scan header"; return false; }
+            const int Ss = seg[1 + 2 * ns], Se = seg[2 + 2 * ns], Ah = seg[3 + 2 * ns] >> 4, Al = seg[3 + 2 * ns] & 15;
+            if (!progressive) { if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) { err = "image: bad spectral selection in a sequential JPEG scan"; return false; } }
+            else if (Ss > Se || Se > 63 || Al > 13 || Ah > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1)) { err = "image: bad progressive JPEG scan parameters"; return false; }
+            const bool dc_scan = Ss == 0, need_ac = !progressive || Ss > 0, need_dc = dc_scan && Ah == 0;
             std::vector<Component*> sc;
             for (int k = 0; k < ns; k++) {
                 Component* c = nullptr;
                 for (auto& cc : comps) if (cc.id == seg[1 + 2 * k]) c = &cc;
                 if (!c) { err = "image: JPEG scan names an unknown component"; return false; }
                 c->td = seg[2 + 2 * k] >> 4; c->ta = seg[2 + 2 * k] & 15;
-                if (c->td > 3 || c->ta > 3 || !dc[c->td].present || !ac[c->ta].present || !have_qt[c->tq]) { err = "image: JPEG scan uses a table that was not defined"; return false; }
+                if (c->td > 3 || c->ta > 3 || (need_dc && !dc[c->td].present) || (need_ac && !ac[c->ta].present)) { err = "image: JPEG scan uses a table that was not defined"; return false; }
                 c->pred = 0;
                 sc.push_back(c);
             }
@@ -242,7 +250,8 @@ bool decode_jpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, 
             const bool single = ns == 1;
             const int ux = single ? (int)(((width * sc[0]->h + hmax - 1) / hmax + 7) / 8) : mcux;
             const int uy = single ? (int)(((height * sc[0]->v + vmax - 1) / vmax + 7) / 8) : mcuy;
-            int since_restart = 0, expected_rst = 0;
+            int since_restart = 0, expected_rst = 0, eobrun = 0;
+            const int p1 = 1 << Al, m1 = -(1 << Al);
             bool ok = true;
             for (int my = 0; my < uy && ok; my++)
                 for (int mx = 0; mx < ux && ok; mx++) {
@@ -254,32 +263,80 @@ bool decode_jpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, 
                         br.pos = p + 2; br.hit_marker = false; br.cnt = 0;
                         expected_rst = (expected_rst + 1) & 7;
                         for (auto* c : sc) c->pred = 0;
+                        eobrun = 0;
                         since_restart = 0;
                     }
                     for (auto* c : sc) {
                         const int nh = single ? 1 : c->h, nv = single ? 1 : c->v;
-                        for (int by = 0; by < nv; by++)
-                            for (int bx = 0; bx < nh; bx++) {
-                                int coef[64];
-                                memset(coef, 0, sizeof(coef));
-                                const int s = decode_symbol(br, dc[c->td], ok);
-                                if (!ok || s > 11) { ok = false; break; }
-                                c->pred += extend(br.bits(s), s);
-                                if (c->pred < -32768 || c->pred > 32767) { ok = false; break; }     // an 8-bit image's DC fits 12 bits: corrupt data
-                                coef[0] = c->pred * (int)qt[c->tq][0];
-                                for (int k = 1; k < 64;) {
-                                    const int rs = decode_symbol(br, ac[c->ta], ok);
-                                    if (!ok) break;
-                                    const int r = rs >> 4, sz = rs & 15;
-                                    if (sz == 0) { if (r == 15) { k += 16; continue; } break; }      // ZRL / EOB
-                                    k += r;
-                                    if (k > 63 || sz > 11) { ok = false; break; }                     // AC categories of 8-bit data are <= 10
-                                    coef[kZigzag[k]] = extend(br.bits(sz), sz) * (int)qt[c->tq][kZigzag[k]];
-                                    k++;
-                                }
-                                if (!ok) break;
+                        for (int by = 0; by < nv && ok; by++)
+                            for (int bx = 0; bx < nh && ok; bx++) {
                                 const int bxx = (single ? mx : mx * c->h + bx), byy = (single ? my : my * c->v + by);
-                                if (bxx < c->bw && byy < c->bh) idct_block(coef, c->plane.data() + ((size_t)byy * 8 * c->bw + bxx) * 8, c->bw * 8);
+                                int16_t scratch[64];
+                                int16_t* blk = (bxx < c->bw && byy < c->bh) ? c->coef.data() + ((size_t)byy * c->bw + bxx) * 64 : scratch;
+                                if (blk == scratch) memset(scratch, 0, sizeof(scratch));
+                                if (dc_scan) {
+                                    if (Ah == 0) {                                        // DC, first pass (F.2.2.1 / G.1.2.1)
+                                        const int sz = decode_symbol(br, dc[c->td], ok);
+                                        if (!ok || sz > 11) { ok = false; break; }
+                                        c->pred += extend(br.bits(sz), sz);
+                                        if (c->pred < -32768 || c->pred > 32767) { ok = false; break; }   // an 8-bit image's DC fits 12 bits: corrupt data
+                                        const int v = c->pred * p1;
+                                        if (v < -32768 || v > 32767) { ok = false; break; }
+                                        blk[0] = (int16_t)v;
+                                    } else if (br.bit()) blk[0] = (int16_t)(blk[0] | p1);   // DC refinement (G.1.2.1)
+                                }
+                                if (!progressive) {                                       // sequential AC (F.2.2.2)
+                                    for (int k = 1; k < 64;) {
+                                        const int rs = decode_symbol(br, ac[c->ta], ok);
+                                        if (!ok) break;
+                                        const int r = rs >> 4, sz = rs & 15;
+                                        if (sz == 0) { if (r == 15) { k += 16; continue; } break; }      // ZRL / EOB
+                                        k += r;
+                                        if (k > 63 || sz > 11) { ok = false; break; }                     // AC categories of 8-bit data are <= 10
+                                        blk[kZigzag[k]] = (int16_t)extend(br.bits(sz), sz);
+                                        k++;
+                                    }
+                                } else if (!dc_scan && Ah == 0) {                         // progressive AC, first pass (G.1.2.2)
+                                    if (eobrun > 0) { eobrun--; continue; }
+                                    for (int k = Ss; k <= Se; k++) {
+                                        const int rs = decode_symbol(br, ac[c->ta], ok);
+                                        if (!ok) break;
+                                        const int r = rs >> 4, sz = rs & 15;
+                                        if (sz) {
+                                            k += r;
+                                            if (k > Se || sz > 11) { ok = false; break; }
+                                            const int v = extend(br.bits(sz), sz) * p1;
+                                            if (v < -32768 || v > 32767) { ok = false; break; }
+                                            blk[kZigzag[k]] = (int16_t)v;
+                                        } else if (r == 15) k += 15;
+                                        else { eobrun = (1 << r) + (r ? br.bits(r) : 0) - 1; break; }
+                                    }
+                                } else if (!dc_scan) {                                    // progressive AC, refinement (G.1.2.3)
+                                    int k = Ss;
+                                    if (eobrun == 0) {
+                                        for (; k <= Se; k++) {
+                                            const int rs = decode_symbol(br, ac[c->ta], ok);
+                                            if (!ok) break;
+                                            int r = rs >> 4, sv = rs & 15;
+                                            if (sv) { if (sv != 1) { ok = false; break; } sv = br.bit() ? p1 : m1; }
+                                            else if (r != 15) { eobrun = (1 << r) + (r ? br.bits(r) : 0); break; }
+                                            do {                                          // pass over nonzero history (correction bits) and r zero coefficients
+                                                int16_t& t = blk[kZigzag[k]];
+                                                if (t != 0) { if (br.bit() && (t & p1) == 0) t = (int16_t)(t + (t >= 0 ? p1 : m1)); }
+                                                else if (--r < 0) break;
+                                                k++;
+                                            } while (k <= Se);
+                                            if (sv && k <= Se) blk[kZigzag[k]] = (int16_t)sv;
+                                        }
+                                    }
+                                    if (ok && eobrun > 0) {
+                                        for (; k <= Se; k++) {
+                                            int16_t& t = blk[kZigzag[k]];
+                                            if (t != 0 && br.bit() && (t & p1) == 0) t = (int16_t)(t + (t >= 0 ? p1 : m1));
+                                        }
+                                        eobrun--;
+                                    }
+                                }
                             }
                         if (!ok) break;
                     }
@@ -297,6 +354,18 @@ bool decode_jpeg(const uint8_t* d, size_t n, uint32_t& width, uint32_t& height, 
         pos += len;
     }
     if (!have_frame || !have_scan) { err = "image: JPEG without image data"; return false; }
+    for (auto& c : comps) {                                            // dequantise + inverse DCT of every block
+        if (!have_qt[c.tq]) { err = "image: JPEG component uses a quantisation table that was not defined"; return false; }
+        c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 128);
+        for (int by = 0; by < c.bh; by++)
+            for (int bx = 0; bx < c.bw; bx++) {
+                const int16_t* q = c.coef.data() + ((size_t)by * c.bw + bx) * 64;
+                int coef[64];
+                for (int k = 0; k < 64; k++) coef[k] = (int)q[k] * (int)qt[c.tq][k];
+                idct_block(coef, c.plane.data() + ((size_t)by * 8 * c.bw + bx) * 8, c.bw * 8);
+            }
+        std::vector<int16_t>().swap(c.coef);
+    }
     channels = (uint32_t)comps.size();
     pixels.resize((size_t)width * height * channels);
     const bool ycc = comps.size() == 3 && adobe_transform != 0;        // JFIF / Adobe transform 1: YCbCr; Adobe transform 0: RGB as is

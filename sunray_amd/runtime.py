@@ -38,7 +38,7 @@ def material_new(base_color, metallic, roughness, emissive_factor, emissive_stre
 
 
 def decode_image(data):
-    """The glTF loader's image decoder on its own (8-bit PNG, baseline JPEG) -> (h, w, channels) uint8."""
+    """The glTF loader's image decoder on its own (8-bit PNG, JPEG) -> (h, w, channels) uint8."""
     buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
     w, h, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
     check(lib().sr_decode_image(buf, C.c_size_t(len(data)), C.byref(w), C.byref(h), C.byref(c), None, C.c_size_t(0)))

@@ -206,10 +206,10 @@ def test_png_decoder_against_reference_decoder(tmp_path):
 
 
 def test_jpeg_decoder_against_libjpeg(tmp_path):
-    """Baseline JPEG textures (what `gltf::import` decodes through the image crate): greyscale, 4:4:4 / 4:2:2 / 4:2:0
-    chroma, optimised Huffman tables, restart intervals, odd extents — against Pillow's libjpeg within the margin JPEG leaves
-    to the decoder (inverse-DCT rounding: a few units; the chroma filters are the IJG ones on both sides). PARITY UNPINNED
-    with respect to the reference's own decoder (zune-jpeg, not under /root/reference). Progressive files are refused."""
+    """JPEG textures (what `gltf::import` decodes through the image crate): baseline and progressive, greyscale, 4:4:4 / 4:2:2 /
+    4:2:0 chroma, optimised Huffman tables, restart intervals, odd extents — against Pillow's libjpeg within the margin JPEG
+    leaves to the decoder (inverse-DCT rounding: a few units; the chroma filters are the IJG ones on both sides). PARITY
+    UNPINNED with respect to the reference's own decoder (zune-jpeg, not under /root/reference)."""
     PIL = pytest.importorskip("PIL.Image")
     import io
     yy, xx = np.mgrid[0:97, 0:131]
@@ -223,7 +223,11 @@ def test_jpeg_decoder_against_libjpeg(tmp_path):
     cases = [(img, dict(quality=90, subsampling=0)), (img, dict(quality=85, subsampling=1)), (img, dict(quality=75, subsampling=2)),
              (img, dict(quality=95, subsampling=2, optimize=True)), (img, dict(quality=80, subsampling=2, restart_marker_blocks=3)),
              (img[..., 0], dict(quality=80)), (noise, dict(quality=60, subsampling=2)), (img[:9, :17], dict(quality=90, subsampling=2)),
-             (img[:8, :8], dict(quality=90, subsampling=0))]
+             (img[:8, :8], dict(quality=90, subsampling=0)),
+             (img, dict(quality=80, progressive=True, subsampling=2)), (img, dict(quality=92, progressive=True, subsampling=0)),
+             (img, dict(quality=60, progressive=True, subsampling=1, restart_marker_blocks=2)), (img[..., 1], dict(quality=75, progressive=True)),
+             (noise, dict(quality=70, progressive=True)), (img[:9, :17], dict(quality=85, progressive=True, subsampling=2))]
+    assert b"\xff\xc2" in enc(img, quality=80, progressive=True)          # the progressive cases really are SOF2 files
     for k, (a, kw) in enumerate(cases):
         data = enc(a, **kw)
         got = rt.decode_image(data)
@@ -244,11 +248,10 @@ def test_jpeg_decoder_against_libjpeg(tmp_path):
     b.write_glb(path)
     parsed = rt.gltf_parse(path)["images"][0]
     assert parsed.shape == (97, 131, 3) and (parsed == rt.decode_image(data)).all()
-    with pytest.raises(SunrayError) as e:
-        rt.decode_image(enc(img, quality=80, progressive=True))
-    assert e.value.code == -5 and "progressive" in e.value.description
-    with pytest.raises(SunrayError):
-        rt.decode_image(data[:len(data) // 2])                    # truncated entropy-coded data / missing EOI must not crash
+    for bad in (data[:len(data) // 2], enc(img, quality=80, progressive=True)[:-40]):
+        with pytest.raises(SunrayError) as e:
+            rt.decode_image(bad)                                   # truncated entropy-coded data is refused, not guessed at
+        assert e.value.code == -5
     assert (rt.decode_image(gltf_util.encode_png(noise)) == noise).all()      # the same entry point decodes PNG by content
 
 

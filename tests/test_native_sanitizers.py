@@ -38,7 +38,8 @@ def test_image_decoders_mutation_fuzz_under_sanitizers(tmp_path):
     import gltf_util
     png = str(tmp_path / "seed.png")
     open(png, "wb").write(gltf_util.encode_png(np.random.default_rng(5).integers(0, 256, size=(9, 14, 4), dtype=np.uint8)))
-    for k, seed in enumerate([os.path.join(ROOT, "tests", "golden", "tiny_420.jpg"), os.path.join(ROOT, "tests", "golden", "tiny_gray.jpg"), png]):
+    for k, seed in enumerate([os.path.join(ROOT, "tests", "golden", "tiny_420.jpg"), os.path.join(ROOT, "tests", "golden", "tiny_gray.jpg"),
+                              os.path.join(ROOT, "tests", "golden", "tiny_prog.jpg"), png]):
         out = subprocess.run([exe, seed, "4000", str(29 + k)], capture_output=True, text=True, env=ENV)
         assert out.returncode == 0 and "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-3000:]
         assert " decoded" in out.stdout and int(out.stdout.split(",")[1].split()[0]) > 50, out.stdout      # many mutants still decode
