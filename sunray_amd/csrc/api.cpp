@@ -891,9 +891,10 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
         e = srk_launch_pass(a, which, s->instrumented, s->dev.shade_tex != nullptr, s->stack_entries, st);
     }
     if (e != 0) return fail(SR_ERR_HIP, std::string(name) + " launch: " + hipGetErrorString((hipError_t)e));
-    // The sweep direction changes rarely (it follows where the expensive rows are): re-derive it after the first launches
-    // of a geometry and then every 16th, not after every launch (a 9 us kernel plus its launch gap per pass).
-    if (sched && (sched->uses++ < 4 || (sched->uses & 15u) == 0u)) {
+    // The schedule changes rarely (it follows where the expensive rows and columns are): re-derive it after the first launches
+    // of a geometry and then every 64th, not after every launch (the kernel is eight workgroups of mostly serial work,
+    // 70-100 us at 1080p, in the stream between two passes: every 16th launch cost 1.3 % of the bench's frame time).
+    if (sched && (sched->uses++ < 4 || (sched->uses & 63u) == 0u)) {
         e = srk_launch_tile_order((const uint32_t*)sched->cost.p, (uint32_t*)sched->order.p, cols, y1 - y0, st);
         if (e != 0) return fail(SR_ERR_HIP, std::string(name) + " tile schedule: " + hipGetErrorString((hipError_t)e));
         sched->have_order = true;
