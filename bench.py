@@ -269,9 +269,8 @@ def main():
     # the next (bit-identical to sequential execution: same CRC). Worth 5-6 % at N = 1 and more on a strip (N > 1: a rank's
     # share is about one round of waves). Per-launch durations then include the time a kernel shares the GPU with its
     # neighbour; SUNRAY_BENCH_PIPELINE=0 runs the passes back to back (undisturbed kernel durations).
-    in_flight = 1 if os.environ.get("SUNRAY_BENCH_PIPELINE", "1") == "0" else int(os.environ.get("SUNRAY_BENCH_FRAMES_IN_FLIGHT", "2"))
-    pipelined = in_flight > 1
-    fpipe = sd.FramePipeline(frame, *[rt.DeviceFrame(W, H, blue_noise, device=device) for _ in range(in_flight - 1)]) if pipelined else None
+    pipelined = os.environ.get("SUNRAY_BENCH_PIPELINE", "1") == "1"
+    fpipe = sd.FramePipeline(frame, rt.DeviceFrame(W, H, blue_noise, device=device)) if pipelined else None
 
     def submit_gather(fr):
         if world > 1:
@@ -310,7 +309,7 @@ def main():
     n_own_pixels = an * (H if axis == "cols" else W)
     halo_cfg = copy.copy(cfg)
     halo_cfg.flags = cfg.flags | abi.TRACE_FLAG_UNCOUNTED
-    iframe = fpipe.frame_for(state["frame"]) if fpipe is not None else frame
+    iframe = fpipe.frames[state["frame"] & 1] if fpipe is not None else frame
     scene.reset_counters()
     scene.trace_ris(iframe, m_i, state["frame"], cfg, tile=own)
     per_kind[KIND_RIS] = scene.counters()
@@ -428,7 +427,7 @@ def main():
                                 "temporal-history exchange (distributed.exchange_history, motion_halo = 0)"
                                 % ("columns" if axis == "cols" else "rows", world, part.sizes(), sd.SPATIAL_HALO))
                                if world > 1 else "single GPU",
-                "frames_in_flight": in_flight,
+                "frames_in_flight": 2 if pipelined else 1,
                 "bvh_build_ms_host": st.build_ms,
                 "last_frame_crc32": frame_crc,
             },

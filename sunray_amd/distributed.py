@@ -198,57 +198,40 @@ def render_strip(scene, frame, matrices, frame_count, cfg, part, rank, motion_ha
 
 
 class FramePipeline:
-    """Several frames in flight on one GPU: raytracing_ris of frame f+1 runs on its own stream while raytracing_final of
-    frame f still drains, so the tail of one launch is filled by the head of the next (the reference keeps
+    """Two frames in flight on one GPU: raytracing_ris of frame f+1 runs on its own stream while raytracing_final of frame
+    f still drains, so the tail of one launch is filled by the head of the next (the reference keeps
     MAX_FRAMES_IN_FLIGHT = 2 frames in flight as well, src/lib.rs:71). What makes it legal: the RIS pass only WRITES the
     G-buffer images and the current reservoir buffers and only READS the previous frame's reservoirs; the final pass
-    reads the G-buffer and the current reservoirs. With `depth` sets of G-buffer images and `depth` physical reservoir
-    buffers (frame f writes buffer f mod depth and reads buffer (f-1) mod depth as history: the kernels index
-    reservoirs[frame_count & 1], so the two pointers handed to a launch are rotated accordingly) the only orderings left
-    are RIS(f) -> final(f), RIS(f) -> RIS(f+1) and final(f-depth) -> RIS(f). Results are those of sequential execution,
-    bit for bit. depth = len(frames). Measured at 1080p on one GPU: 2.04 ms per frame with one frame in flight, 1.93 with two,
-    1.94 with three (the third buys nothing: RIS(f+1) and final(f) start together and end together either way), and 1.98
-    with the RIS stream at high priority — two frames, equal priority is what bench.py runs."""
+    reads the G-buffer and the current reservoirs. With the G-buffer double-buffered (two frame objects that share
+    their reservoir arrays) the only orderings left are RIS(f) -> final(f), RIS(f) -> RIS(f+1) and final(f-2) -> RIS(f).
+    Results are those of sequential execution, bit for bit (test_frames_in_flight_equal_sequential_frames).
+    Two is also the limit: a third frame in flight needs a third physical reservoir buffer, and the reference's reservoirs are
+    a two-buffer ping-pong whose STALE contents are observable — a sky pixel leaves its GI reservoir unwritten
+    (ray_gen_ris.slang:171), so a pixel that reprojects onto last frame's sky reads what was stored there three frames ago;
+    with three rotating buffers that would be four frames ago (tried: identical for a static camera, different bits for a
+    moving one, and no faster — 1.94 vs 1.93 ms per frame)."""
 
-    def __init__(self, *frames):
+    def __init__(self, frame_a, frame_b):
         import torch
-        self.frames = list(frames)
-        self.depth = len(self.frames)
-        assert self.depth >= 2
-        a = self.frames[0]
-        z = lambda t: torch.zeros_like(t)
-        # physical reservoir buffers: frame 0's two, plus fresh ones for deeper pipelines
-        self.res = [a.reservoirs[0], a.reservoirs[1]] + [z(a.reservoirs[0]) for _ in range(self.depth - 2)]
-        self.res_gi = [a.reservoirs_gi[0], a.reservoirs_gi[1]] + [z(a.reservoirs_gi[0]) for _ in range(self.depth - 2)]
-        for fr in self.frames:
-            fr.reservoirs, fr.reservoirs_gi = [None, None], [None, None]
+        frame_b.reservoirs, frame_b.reservoirs_gi = frame_a.reservoirs, frame_a.reservoirs_gi
+        self.frames = [frame_a, frame_b]
         self.s_ris, self.s_final = torch.cuda.Stream(), torch.cuda.Stream()
-        self.ev_ris = [torch.cuda.Event() for _ in range(self.depth)]
-        self.ev_final = [torch.cuda.Event() for _ in range(self.depth)]
+        self.ev_ris = [torch.cuda.Event(), torch.cuda.Event()]
+        self.ev_final = [torch.cuda.Event(), torch.cuda.Event()]
         self.torch = torch
-
-    def frame_for(self, frame_count):
-        """The frame object of frame `frame_count`, its reservoir pointers rotated: [frame_count & 1] = this frame's buffer,
-        the other one = the previous frame's."""
-        fr = self.frames[frame_count % self.depth]
-        cur = frame_count & 1
-        fr.reservoirs[cur], fr.reservoirs[cur ^ 1] = self.res[frame_count % self.depth], self.res[(frame_count - 1) % self.depth]
-        fr.reservoirs_gi[cur], fr.reservoirs_gi[cur ^ 1] = self.res_gi[frame_count % self.depth], self.res_gi[(frame_count - 1) % self.depth]
-        return fr
 
     def step(self, scene, matrices, frame_count, cfg, part, rank, after_final=None, motion_halo=0):
         torch = self.torch
-        k = frame_count % self.depth
-        fr = self.frame_for(frame_count)
+        k = frame_count & 1
+        fr = self.frames[k]
         with torch.cuda.stream(self.s_ris):
-            self.s_ris.wait_event(self.ev_final[k])          # final(f - depth) has finished reading this image set and reservoir buffer
+            self.s_ris.wait_event(self.ev_final[k])          # final(f-2) has finished reading this G-buffer
             trace_ris_strip(scene, fr, matrices, frame_count, cfg, part, rank)
             if cfg.enable_restir:
                 exchange_history(fr, frame_count, part, rank, motion_halo)   # ordered on the RIS stream (RIS(f+1) reads it)
             self.ev_ris[k].record(self.s_ris)
         with torch.cuda.stream(self.s_final):
             self.s_final.wait_event(self.ev_ris[k])
-            fr = self.frame_for(frame_count)
             trace_final_strip(scene, fr, matrices, frame_count, cfg, part, rank)
             self.ev_final[k].record(self.s_final)
             if after_final is not None:

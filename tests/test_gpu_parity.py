@@ -392,6 +392,36 @@ def test_row_tiles_compose_to_full_frame(rt, blue_noise):
     assert_bits_equal(a["reservoirs"][0], b["reservoirs"][0], "tiled reservoirs")
 
 
+def test_frames_in_flight_equal_sequential_frames(rt, blue_noise):
+    """distributed.FramePipeline: RIS of frame f+1 on its own stream while the final pass of frame f runs, two G-buffer sets
+    sharing the reservoir ping-pong — the frames are those of sequential execution, bit for bit (moving camera over sky and
+    geometry, so temporal reuse reads real history, including the stale GI reservoirs sky pixels leave behind)."""
+    import torch
+    from sunray_amd import distributed as sd
+    desc = scenes.cornell_glass_mirror()
+    W, H, frames = 200, 152, 7
+    cfg = abi.SrTraceConfig.reference()
+    part = sd.Partition(W, H, 1)
+    gsc = rt.Scene(0).load(desc)
+    mats, prev = [], None
+    for f in range(frames):
+        m = rt.camera_matrices((desc.camera_pos[0] + 0.03 * f, desc.camera_pos[1], desc.camera_pos[2]), desc.camera_target, desc.fov_y, W, H, prev)
+        prev = list(m.view_proj)
+        mats.append(m)
+    seq = rt.DeviceFrame(W, H, blue_noise)
+    want = []
+    for f in range(frames):
+        gsc.trace_ris(seq, mats[f], f, cfg); gsc.trace_final(seq, mats[f], f, cfg)
+        want.append(seq.raw_color.cpu().numpy().copy())
+    fp = sd.FramePipeline(rt.DeviceFrame(W, H, blue_noise), rt.DeviceFrame(W, H, blue_noise))
+    got = []
+    for f in range(frames):
+        fp.step(gsc, mats[f], f, cfg, part, 0, after_final=lambda fr: got.append(fr.raw_color.clone()))   # cloned on the final stream, in order
+    torch.cuda.synchronize()
+    for f in range(frames):
+        assert_bits_equal(want[f], got[f].cpu().numpy(), "frame %d with two frames in flight" % f)
+
+
 def test_empty_scene_renders_sky(rt, blue_noise):
     g = rt.Scene(0); g.set_instances([])
     W, H = 64, 48
