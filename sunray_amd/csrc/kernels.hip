@@ -1,7 +1,8 @@
 // HIP kernels of the ray-tracing hot path for gfx950 (MI355X).
 //
-//   trace_closest_kernel / trace_any_kernel  — persistent-threads ray-queue tracers (K2 / K3)
+//   trace_queue_kernel<ANY>                  — persistent-threads ray-queue tracers (K2 / K3)
 //   shade_closest_hit_kernel                 — closest_hit.slang / ray_miss.slang on hit records (K4/K6)
+//   any_hit_kernel                           — any_hit.slang's alpha test on hit records (K5; never part of a traversal)
 //   ris_kernel                               — ray_gen_ris.slang:12-440   (K1, K7, K8, K9)
 //   final_kernel                             — ray_gen_final.slang:11-436 (K1, K10)
 //

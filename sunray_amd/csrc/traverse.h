@@ -4,7 +4,8 @@
 //
 // Data layout in HBM:
 //   nodes : 4-wide BVH with quantised child boxes, 64 bytes per node = 4 x 16-byte gathers per step
-//           (traversal is bound by vector-L1 tag lookups — one per gather per lane — not by HBM):
+//           (a step lasts as long as the slowest of its lanes' gathers — under load one of them nearly always misses L2 —
+//           not as long as its tag lookups or its arithmetic: DESIGN.md §5, round-2 experiments):
 //           [0]  origin.xyz | exponents ex | ey<<8 | ez<<16     plane = fmaf(q, 2^e, origin)
 //           [16] LX LY LZ HX   one dword per plane set, byte c = child c
 //           [32] HY HZ - -
