@@ -592,9 +592,6 @@ int sr_scene_read_counters(SrScene* scene, void* stream, SrRayCounters* out);
 /* Instrumented kernels (count child boxes / triangle records tested, SURVEY §8d B_ray accounting).
  * Off by default: the counting costs registers and time. */
 int sr_scene_set_instrumented(SrScene* scene, int on);
-/* Instrumented build only: the ray with the most box tests (> 20000) since the last counter reset.
- * out10[0] = box tests (0 = none), out10[1] = 1 for an any-hit query, out10[2..9] = the SrRay bits. */
-int sr_scene_debug_worst_ray(SrScene* scene, uint32_t* out10);
 
 /* Per-launch device timing: when enabled every sr_trace_* launch is bracketed by a HIP event pair
  * recorded on the launch's own stream. sr_scene_read_timing waits for the recorded launches of one

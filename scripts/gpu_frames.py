@@ -19,7 +19,4 @@ for f in range(n):
     c = sc.counters()
     a, _ = sc.read_timing(0); b, _ = sc.read_timing(1)
     rc = fr.raw_color
-    if len(sys.argv) > 2:
-        w = sc.debug_worst_ray()
-        if w[0]: print('   worst ray: boxes', w[0], 'any' if w[1] else 'closest', w[2].tolist(), [hex(x) for x in w[2].view(np.uint32)])
     print("frame %2d ris %7.3f ms final %7.3f ms closest %d any %d nan %d inf %d" % (f, a, b, c.closest_queries, c.any_queries, int(torch.isnan(rc).sum()), int(torch.isinf(rc).sum())), flush=True)

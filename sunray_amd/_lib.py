@@ -20,7 +20,7 @@ SYMBOLS = [
     "sr_renderer_render_to_host_memory", "sr_renderer_get", "sr_decode_image", "sr_gltf_open", "sr_gltf_close", "sr_gltf_counts", "sr_gltf_blas", "sr_gltf_instance", "sr_gltf_image",
     "sr_gltf_sampler", "sr_gltf_texture", "sr_renderer_load_gltf", "sr_renderer_load_scene", "sr_loaded_scene_get", "sr_loaded_scene_destroy",
     "sr_renderer_unload_scene", "sr_renderer_unload_mesh", "sr_default_noise_texture",
-    "sr_scene_read_tile_row_costs", "sr_scene_read_tile_costs", "sr_scene_reset_counters", "sr_scene_read_counters", "sr_scene_set_instrumented", "sr_scene_debug_worst_ray", "sr_scene_enable_timing",
+    "sr_scene_read_tile_row_costs", "sr_scene_read_tile_costs", "sr_scene_reset_counters", "sr_scene_read_counters", "sr_scene_set_instrumented", "sr_scene_enable_timing",
     "sr_scene_read_timing",
 ]
 

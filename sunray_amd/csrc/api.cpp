@@ -69,7 +69,7 @@ struct DeviceBuffer {
 
 }  // namespace
 
-constexpr size_t kQueueHeadOffset = 256;   // d_misc: [0,32) ray counters, [64,128) diagnostics, [256, 256 + 16 * kQueueHeads) queue heads
+constexpr size_t kQueueHeadOffset = 256;   // d_misc: [0,32) ray counters, [256, 256 + 16 * kQueueHeads) queue heads
 constexpr uint32_t kQueueHeads = 64;
 
 struct SrScene {
@@ -984,7 +984,6 @@ int sr_scene_reset_counters(SrScene* s, void* stream) {
     int rc = bind_device(s);
     if (rc != SR_OK) return rc;
     HIP_TRY(hipMemsetAsync(s->d_misc.p, 0, 32, (hipStream_t)stream));
-    HIP_TRY(hipMemsetAsync((char*)s->d_misc.p + 64, 0, 64, (hipStream_t)stream));
     return SR_OK;
 }
 
@@ -996,20 +995,6 @@ int sr_scene_read_counters(SrScene* s, void* stream, SrRayCounters* out) {
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     HIP_TRY(hipMemcpy(v, s->d_misc.p, sizeof(v), hipMemcpyDeviceToHost));
     out->closest_queries = v[0]; out->any_queries = v[1]; out->boxes_tested = v[2]; out->tris_tested = v[3];
-    return SR_OK;
-}
-
-// Diagnostics of the instrumented build: the ray with the most box tests (> 20000) since the last
-// counter reset: out[0] = box tests, out[1] = 1 for an any-hit query, out[2..9] = the SrRay as float bits.
-int sr_scene_debug_worst_ray(SrScene* s, uint32_t* out10) {
-    if (!s || !out10) return fail(SR_ERR_INVALID_ARG, "sr_scene_debug_worst_ray: null argument");
-    int rc = bind_device(s);
-    if (rc != SR_OK) return rc;
-    uint32_t v[16];
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(v, (char*)s->d_misc.p + 64, sizeof(v), hipMemcpyDeviceToHost));
-    out10[0] = v[0]; out10[1] = v[1];
-    for (int i = 0; i < 8; i++) out10[2 + i] = v[8 + i];
     return SR_OK;
 }
 

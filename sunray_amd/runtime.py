@@ -344,12 +344,6 @@ class Scene:
     def set_instrumented(self, on):
         check(lib().sr_scene_set_instrumented(self._h, C.c_int(1 if on else 0)))
 
-    def debug_worst_ray(self):
-        out = (C.c_uint32 * 10)()
-        check(lib().sr_scene_debug_worst_ray(self._h, out))
-        ray = np.array(list(out)[2:], dtype=np.uint32).view(np.float32)
-        return out[0], out[1], ray
-
     def enable_timing(self, on):
         check(lib().sr_scene_enable_timing(self._h, C.c_int(1 if on else 0)))
 
