@@ -44,7 +44,6 @@ int srk_launch_pass(const srd::PassArgs& args, int which, int stats, int texture
 int srk_lds_rows(int stack_entries);
 uint32_t srk_pass_tile_count(uint32_t width, uint32_t rows);
 uint32_t srk_pass_order_cap(uint32_t width, uint32_t rows);
-uint32_t srk_pass_tiles_x(uint32_t width);
 int srk_launch_tile_order(const uint32_t* tile_cost, uint32_t* tile_order, uint32_t width, uint32_t rows, hipStream_t stream);
 
 int srk_launch_post_temporal(const SrPostParams& p, hipStream_t stream);

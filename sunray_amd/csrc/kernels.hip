@@ -998,7 +998,6 @@ int srk_launch_pass(const PassArgs& args_in, int which, int stats, int textured,
 int srk_lds_rows(int stack_entries) { return stack_entries + kLdsExtraRows; }   // LDS rows (of one int per thread) a block needs
 
 uint32_t srk_pass_tile_count(uint32_t width, uint32_t rows) { return ((width + kPassTile - 1) / kPassTile) * ((rows + kPassTile - 1) / kPassTile); }
-uint32_t srk_pass_tiles_x(uint32_t width) { return (width + kPassTile - 1) / kPassTile; }
 
 // Entries per XCD of the tile schedule (= blocks per XCD of a pass launch): the widest band the schedule may form.
 uint32_t srk_pass_order_cap(uint32_t width, uint32_t rows) {
