@@ -74,7 +74,7 @@ def requested_bytes(c, n_pixels, which):
     return b
 
 
-def live_pmc(argv_tail, timeout_s=150):
+def live_pmc(argv_tail, timeout_s=75):
     """Physical counters of THIS run's workload, measured now: one `rocprofv3 --pmc <group> -- python3 bench.py ...`
     child per counter group (separate passes, the program itself after `--`), started before this process touches the
     GPU. Returns {kernel: {counter: mean per launch}} plus provenance, or {"error": ...}: the bench line then carries
