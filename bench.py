@@ -199,6 +199,7 @@ def main():
 
     # Physical counters of this very workload, measured before this process touches the GPU (N = 1 only).
     pmc = None
+    import torch      # no GPU call yet: importing pages the libraries in (1-2 minutes on a fresh box), so the children below start fast
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_pmc:
         pmc = live_pmc(["--gpus", "1", "--steps", "3", "--warmup", "3", "--no-cpu-baseline", "--no-pmc",
                         "--width", str(args.width), "--height", str(args.height), "--grid", str(args.grid)])
