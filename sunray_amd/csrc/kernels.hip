@@ -627,7 +627,7 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
 
     bool in_loop = active;
     for (int bounce = 0; bounce < BOUNCES; bounce++) {                                 // :74
-        if (__ballot(in_loop) == 0ull) break;
+        if (__builtin_amdgcn_ballot_w64(in_loop) == 0ull) break;
         ws_query<V, false>(cx, in_loop, rayOrigin, rayDir, 0.001f, 10000.0f, h);
         bool do_restir = false, do_nee = false, do_bounce = false;
         f3 hit_normal = splat(0.0f), hit_albedo = splat(0.0f), hitPos = splat(0.0f), V_view = splat(0.0f);
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
         }
 
         // ---- :136-327 first rough hit: ReSTIR DI + GI spatial reuse, then the walk stops ----
-        if (__ballot(do_restir) != 0ull) {
+        if (__builtin_amdgcn_ballot_w64(do_restir) != 0ull) {
             SrReservoir spatial_r; zero_reservoir(spatial_r);
             f3 f_y_winner = splat(0.0f), shadow_dir = splat(0.0f);
             float shadow_dist = 0.0f;
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
         }
 
         // ---- :328-382 later rough bounces: one NEE sample ----
-        if (__ballot(do_nee) != 0ull) {
+        if (__builtin_amdgcn_ballot_w64(do_nee) != 0ull) {
             bool nee_pending = false, want_nee = false;
             f3 shadow_ray_dir = splat(0.0f), nee_emission = splat(0.0f);
             float light_dist = 0.0f, cos_theta_light = 0.0f, cos_theta_surface = 0.0f, light_area = 0.0f;

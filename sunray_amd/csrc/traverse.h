@@ -210,16 +210,16 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
             if (ANY) { if (k == 0ull) { node = kSentinel; sp = sb; } }        // somebody found an occluder
             else if (k != ~0ull) { const float ts = unord_f32((uint32_t)(k >> 32)); cull = fminf(cull, fmaf(fabsf(ts), 1e-5f, ts)); }
         }
-        if (__ballot(node != kSentinel) == 0ull) break;
+        if (__builtin_amdgcn_ballot_w64(node != kSentinel) == 0ull) break;
         // ---- node phase: wave-uniform loop, so that lanes without work stay in step and can be handed some ----
         for (;;) {
             const bool inner = node >= 0 && node != kSentinel;
-            if (__ballot(inner && leaf == 0) == 0ull) break;   // every walking lane holds a (postponed) leaf: on to the triangles
+            if (__builtin_amdgcn_ballot_w64(inner && leaf == 0) == 0ull) break;   // every walking lane holds a (postponed) leaf: on to the triangles
             const bool idle = node == kSentinel && leaf == 0;
-            const unsigned long long idle_mask = __ballot(idle);
+            const unsigned long long idle_mask = __builtin_amdgcn_ballot_w64(idle);
             if (idle_mask != 0ull) {
                 const bool can_give = inner && sp > sb;
-                const unsigned long long donor_mask = __ballot(can_give);
+                const unsigned long long donor_mask = __builtin_amdgcn_ballot_w64(can_give);
                 if (donor_mask != 0ull) {
                     const uint32_t n = min((uint32_t)__popcll(idle_mask), (uint32_t)__popcll(donor_mask));
                     const uint32_t drank = lanes_below(donor_mask), irank = lanes_below(idle_mask);
