@@ -51,7 +51,7 @@ print("%dx%d, 999 714 triangles, reference constants, two frames in flight: 1 GP
 tiles_x = (W + 7) // 8
 tc = sc.tile_costs(0, W, 0, H).astype(np.float64) + sc.tile_costs(1, W, 0, H)
 for world in worlds:
-    for axis in ("rows", "cols"):
+    for axis in os.environ.get("STRIP_AXES", "rows,cols").split(","):
         L = W if axis == "cols" else H
         cost = sd.axis_cost_from_tiles(tc, tiles_x, axis, L)
         for name, bounds in (("equal", None), ("equal-cost", sd.balanced_bounds(cost, world, min_size=sd.SPATIAL_HALO + 2))):
