@@ -536,6 +536,10 @@ int sr_renderer_render_to_host_memory(SrRenderer* renderer, const float cam_pos[
 typedef struct SrGltf SrGltf;
 /* The loader's image decoder on its own: extent + channels, and the pixels when `pixels` != NULL (cap >= w*h*channels). */
 int sr_decode_image(const uint8_t* data, size_t n, uint32_t* width, uint32_t* height, uint32_t* channels, uint8_t* pixels, size_t cap);
+/* image::load_from_memory(bytes).to_rgba8() — lib.rs:281-283 (the embedded blue-noise texture, a 16-bit greyscale PNG) and the png
+ * example's host side: any PNG / JPEG above plus 16-bit PNG, widened to RGBA8 (grey -> r = g = b, no alpha -> 255, 16-bit sample v ->
+ * (v + 128) / 257 as image-rs 0.25 narrows it). `pixels` may be NULL to query the extent; cap >= w * h * 4. */
+int sr_decode_image_rgba8(const uint8_t* data, size_t n, uint32_t* width, uint32_t* height, uint8_t* pixels, size_t cap);
 int sr_gltf_open(const char* path, SrGltf** out);
 int sr_gltf_close(SrGltf* gltf);
 int sr_gltf_counts(const SrGltf* gltf, uint32_t* n_blases, uint32_t* n_instances, uint32_t* n_images,
@@ -574,6 +578,10 @@ int sr_renderer_get(SrRenderer* renderer, SrScene** scene, const uint32_t** outp
 /* Stand-in for the reference's embedded 128x128 blue-noise PNG (lib.rs:281-309; an input asset, not
  * copied): hashed white noise, RGBA8, grey in rgb, alpha 255. Host pointer, w*h*4 bytes. */
 int sr_default_noise_texture(uint32_t w, uint32_t h, uint32_t seed, uint8_t* out_rgba8);
+/* Replaces the noise texture of the passes (lib.rs:281-309 builds it once, in Renderer::new, from the PNG embedded in the crate: a host
+ * that owns that asset decodes it with sr_decode_image_rgba8 and hands it over here). RGBA8 texels in host memory, w * h * 4 bytes.
+ * Waits for the frames in flight; the temporal history is kept. */
+int sr_renderer_set_blue_noise(SrRenderer* r, const uint8_t* rgba8, uint32_t w, uint32_t h);
 
 /* Measured cost of the last launch of pass `which` (0 = raytracing_ris, 1 = raytracing_final) with this launch
  * geometry, summed per tile row (8 pixel rows), in shader cycles: the data the library's own tile schedule uses.

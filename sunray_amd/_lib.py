@@ -17,7 +17,7 @@ SYMBOLS = [
     "sr_scene_get_tables", "sr_scene_bvh_stats", "sr_scene_resolve_triangle", "sr_host_bvh_build", "sr_host_bvh_get",
     "sr_host_bvh_destroy", "sr_trace_closest", "sr_trace_any", "sr_shade_closest_hit", "sr_any_hit_ignores", "sr_trace_ris", "sr_trace_final", "sr_post_temporal", "sr_post_denoise", "sr_post_tonemap", "sr_renderer_create", "sr_renderer_destroy",
     "sr_renderer_resize", "sr_renderer_add_start_of_frame_callback", "sr_renderer_add_end_of_frame_callback", "sr_renderer_add_resize_callback", "sr_renderer_load_mesh", "sr_renderer_set_config", "sr_renderer_render", "sr_renderer_wait_frame",
-    "sr_renderer_render_to_host_memory", "sr_renderer_get", "sr_decode_image", "sr_gltf_open", "sr_gltf_close", "sr_gltf_counts", "sr_gltf_blas", "sr_gltf_instance", "sr_gltf_image",
+    "sr_renderer_render_to_host_memory", "sr_renderer_get", "sr_decode_image", "sr_decode_image_rgba8", "sr_renderer_set_blue_noise", "sr_gltf_open", "sr_gltf_close", "sr_gltf_counts", "sr_gltf_blas", "sr_gltf_instance", "sr_gltf_image",
     "sr_gltf_sampler", "sr_gltf_texture", "sr_renderer_load_gltf", "sr_renderer_load_scene", "sr_loaded_scene_get", "sr_loaded_scene_destroy",
     "sr_renderer_unload_scene", "sr_renderer_unload_mesh", "sr_default_noise_texture",
     "sr_scene_read_tile_row_costs", "sr_scene_read_tile_costs", "sr_scene_reset_counters", "sr_scene_read_counters", "sr_scene_set_instrumented", "sr_scene_enable_timing",

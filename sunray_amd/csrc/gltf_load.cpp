@@ -171,9 +171,12 @@ uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1
 
 // PNG (ISO/IEC 15948) -> 8-bit pixels the way image-rs hands them to the gltf crate: greyscale = R8, grey+alpha =
 // R8G8, truecolour = R8G8B8, truecolour+alpha = R8G8B8A8, palette = expanded to RGB (RGBA with tRNS); bit depths
-// 1/2/4 are scaled to 8. 16-bit PNGs map to R16* formats, which Image::new_from_data does not handle (todo!(),
-// image/mod.rs:102-107) -> rejected here too. Adam7 interlacing is not supported.
-bool decode_png(const uint8_t* d, size_t n, DecodedImage& out, std::string& err) {
+// 1/2/4 are scaled to 8; a tRNS chunk of a greyscale / truecolour image becomes an alpha channel (the png crate's EXPAND
+// transformation: alpha 0 where the pixel equals the chunk's colour at the file's bit depth, else opaque). 16-bit PNGs map to
+// R16* formats, which Image::new_from_data does not handle (todo!(), image/mod.rs:102-107) -> rejected for glTF textures;
+// `allow16` (the to_rgba8 path of lib.rs:281-283) narrows every 16-bit sample v to (v + 128) / 257, image-rs 0.25's
+// u16 -> u8 conversion. Adam7 interlacing is not supported.
+bool decode_png(const uint8_t* d, size_t n, DecodedImage& out, std::string& err, bool allow16 = false) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     if (n < 8 || memcmp(d, sig, 8) != 0) { err = "image: not a PNG"; return false; }
     size_t pos = 8;
@@ -194,9 +197,9 @@ bool decode_png(const uint8_t* d, size_t n, DecodedImage& out, std::string& err)
     if (w == 0 || h == 0 || ctype < 0) { err = "image: PNG without IHDR"; return false; }
     if (w > 32768 || h > 32768) { err = "image: PNG larger than 32768 pixels on a side"; return false; }
     if (interlace) { err = "image: interlaced PNG is not supported"; return false; }
-    if (depth == 16) { err = "image: 16-bit PNG maps to an R16 format the reference's Image::new_from_data does not handle (image/mod.rs:102-107)"; return false; }
+    if (depth == 16 && !allow16) { err = "image: 16-bit PNG maps to an R16 format the reference's Image::new_from_data does not handle (image/mod.rs:102-107)"; return false; }
     int samples = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!samples || (depth != 8 && depth != 4 && depth != 2 && depth != 1) || (depth < 8 && ctype != 0 && ctype != 3)) { err = "image: unsupported PNG colour type / bit depth"; return false; }
+    if (!samples || (depth != 16 && depth != 8 && depth != 4 && depth != 2 && depth != 1) || (depth < 8 && ctype != 0 && ctype != 3) || (depth == 16 && ctype == 3)) { err = "image: unsupported PNG colour type / bit depth"; return false; }
     const size_t bpp_bits = (size_t)samples * depth, stride = ((size_t)w * bpp_bits + 7) / 8, bpp = (bpp_bits + 7) / 8;
     // deflate expands at most ~1032:1: refuse a header that promises more than the IDAT bytes can hold before allocating for it
     if ((stride + 1) * (size_t)h > idat.size() * 1032 + 65536) { err = "image: PNG IDAT data too short for the extent in its header"; return false; }
@@ -221,6 +224,7 @@ bool decode_png(const uint8_t* d, size_t n, DecodedImage& out, std::string& err)
     auto sample = [&](uint32_t y, size_t i) -> uint32_t {   // i-th sample of row y at `depth` bits
         const uint8_t* row = img.data() + stride * y;
         if (depth == 8) return row[i];
+        if (depth == 16) return ((uint32_t)row[2 * i] << 8) | row[2 * i + 1];
         const size_t bit = i * depth;
         return (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1);
     };
@@ -239,11 +243,24 @@ bool decode_png(const uint8_t* d, size_t n, DecodedImage& out, std::string& err)
             }
         return true;
     }
-    out.channels = (uint32_t)samples;
-    out.pixels.resize((size_t)w * h * samples);
-    const uint32_t scale = depth == 8 ? 1 : 255u / ((1u << depth) - 1);
+    // tRNS of a greyscale (2 bytes) or truecolour (6 bytes) image: one transparent colour, 16 bits per sample in the chunk
+    const bool keyed = (ctype == 0 && trns.size() >= 2) || (ctype == 2 && trns.size() >= 6);
+    uint32_t key[3] = {0, 0, 0};
+    for (int c = 0; keyed && c < samples; c++) key[c] = (((uint32_t)trns[2 * c] << 8) | trns[2 * c + 1]) & ((1u << depth) - 1);
+    out.channels = (uint32_t)samples + (keyed ? 1u : 0u);
+    out.pixels.resize((size_t)w * h * out.channels);
+    const uint32_t scale = depth >= 8 ? 1 : 255u / ((1u << depth) - 1);
     for (uint32_t y = 0; y < h; y++)
-        for (size_t i = 0; i < (size_t)w * samples; i++) out.pixels[(size_t)y * w * samples + i] = (uint8_t)(sample(y, i) * scale);
+        for (uint32_t x = 0; x < w; x++) {
+            uint8_t* q = &out.pixels[((size_t)y * w + x) * out.channels];
+            bool is_key = keyed;
+            for (int c = 0; c < samples; c++) {
+                const uint32_t v = sample(y, (size_t)x * samples + c);
+                if (keyed && v != key[c]) is_key = false;
+                q[c] = depth == 16 ? (uint8_t)((v + 128u) / 257u) : (uint8_t)(v * scale);
+            }
+            if (keyed) q[samples] = is_key ? 0 : 255;
+        }
     return true;
 }
 
@@ -666,6 +683,26 @@ bool decode_image(const uint8_t* data, size_t n, uint32_t& width, uint32_t& heig
     width = im.w; height = im.h; channels = im.channels; pixels.swap(im.pixels);
     return true;
 }
+// image::load_from_memory(bytes).to_rgba8() (lib.rs:281-283, the embedded blue-noise PNG — 16-bit greyscale in the reference):
+// any supported PNG / JPEG widened to RGBA8 — grey replicated to r, g, b; missing alpha = 255; 16-bit samples narrowed.
+bool decode_image_rgba8(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba, std::string& err) {
+    uint32_t ch = 0;
+    std::vector<uint8_t> px;
+    if (n >= 3 && data[0] == 0xFF && data[1] == 0xD8) { if (!decode_jpeg(data, n, width, height, ch, px, err)) return false; }
+    else {
+        DecodedImage im;
+        if (!decode_png(data, n, im, err, true)) return false;
+        width = im.w; height = im.h; ch = im.channels; px.swap(im.pixels);
+    }
+    rgba.resize((size_t)width * height * 4);
+    for (size_t i = 0; i < (size_t)width * height; i++) {
+        const uint8_t* p = &px[i * ch];
+        uint8_t* q = &rgba[i * 4];
+        if (ch <= 2) { q[0] = q[1] = q[2] = p[0]; q[3] = ch == 2 ? p[1] : 255; }
+        else { q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = ch == 4 ? p[3] : 255; }
+    }
+    return true;
+}
 }  // namespace srh
 
 extern "C" {
@@ -679,6 +716,20 @@ int sr_decode_image(const uint8_t* data, size_t n, uint32_t* width, uint32_t* he
     if (!srh::decode_image(data, n, *width, *height, *channels, px, err)) return srh::set_error(SR_ERR_UNSUPPORTED, err);
     if (pixels) {
         if (cap < px.size()) return srh::set_error(SR_ERR_INVALID_ARG, "sr_decode_image: output too small");
+        memcpy(pixels, px.data(), px.size());
+    }
+    return SR_OK;
+}
+
+// image::load_from_memory(..).to_rgba8(): what the reference does with its embedded blue-noise texture (lib.rs:281-284) and what
+// a host does with any image it wants as RGBA8. 16-bit PNG samples are narrowed as image-rs does; w * h * 4 bytes.
+int sr_decode_image_rgba8(const uint8_t* data, size_t n, uint32_t* width, uint32_t* height, uint8_t* pixels, size_t cap) {
+    if (!data || !width || !height) return srh::set_error(SR_ERR_INVALID_ARG, "sr_decode_image_rgba8: null argument");
+    std::vector<uint8_t> px;
+    std::string err;
+    if (!srh::decode_image_rgba8(data, n, *width, *height, px, err)) return srh::set_error(SR_ERR_UNSUPPORTED, err);
+    if (pixels) {
+        if (cap < px.size()) return srh::set_error(SR_ERR_INVALID_ARG, "sr_decode_image_rgba8: output too small");
         memcpy(pixels, px.data(), px.size());
     }
     return SR_OK;

@@ -92,6 +92,7 @@ void tree_levels(const std::vector<uint32_t>& nodes, std::vector<uint32_t>& leve
 bool decode_jpeg(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height, uint32_t& channels, std::vector<uint8_t>& pixels, std::string& err);
 // PNG / JPEG by content, as the loader decodes glTF images (gltf_load.cpp)
 bool decode_image(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height, uint32_t& channels, std::vector<uint8_t>& pixels, std::string& err);
+bool decode_image_rgba8(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba, std::string& err);
 
 // the one thread-local error slot of the library (api.cpp); returns `code`
 int set_error(int code, const std::string& msg);

@@ -33,6 +33,7 @@ struct SrRenderer {
     hipEvent_t ev_in = nullptr, ev_ris[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     int last_set = 0;
     uint8_t* blue_noise = nullptr;
+    uint32_t noise_w = 128, noise_h = 128;
     // per-frame state
     float prev_view_proj[16];       // zero on the first frame (lib.rs:410), NOT reset by resize
     uint32_t relative_frame_count = 0;
@@ -140,6 +141,18 @@ int sr_renderer_create(int device, uint32_t width, uint32_t height, SrRenderer**
         return rfail(SR_ERR_HIP, "Renderer::new: blue-noise upload failed");
     }
     *out = r;
+    return SR_OK;
+}
+
+int sr_renderer_set_blue_noise(SrRenderer* r, const uint8_t* rgba8, uint32_t w, uint32_t h) {
+    if (!r || !rgba8 || w == 0 || h == 0 || w > 16384 || h > 16384) return rfail(SR_ERR_INVALID_ARG, "sr_renderer_set_blue_noise: bad argument");
+    if (hipSetDevice(r->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return rfail(SR_ERR_HIP, "sr_renderer_set_blue_noise: device");
+    uint8_t* fresh = nullptr;
+    const size_t bytes = (size_t)w * h * 4;
+    if (hipMalloc((void**)&fresh, bytes) != hipSuccess) return rfail(SR_ERR_HIP, "sr_renderer_set_blue_noise: out of device memory");
+    if (hipMemcpy(fresh, rgba8, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(fresh); return rfail(SR_ERR_HIP, "sr_renderer_set_blue_noise: upload failed"); }
+    if (r->blue_noise) (void)hipFree(r->blue_noise);
+    r->blue_noise = fresh; r->noise_w = w; r->noise_h = h;
     return SR_OK;
 }
 
@@ -269,7 +282,7 @@ int sr_renderer_render(SrRenderer* r, const float cam_pos[3], const float cam_ta
     p.scene = r->scene;
     p.raw_color = r->raw_color[k]; p.depth_img = r->depth[k]; p.normal_img = r->normal[k]; p.diffuse_img = r->diffuse[k]; p.motion_vec_img = r->motion[k];
     p.matrices = &m;
-    p.blue_noise_tex = r->blue_noise; p.blue_noise_w = 128; p.blue_noise_h = 128;
+    p.blue_noise_tex = r->blue_noise; p.blue_noise_w = r->noise_w; p.blue_noise_h = r->noise_h;
     p.reservoirs[0] = r->reservoirs[0]; p.reservoirs[1] = r->reservoirs[1];
     p.reservoirs_gi[0] = r->reservoirs_gi[0]; p.reservoirs_gi[1] = r->reservoirs_gi[1];
     p.frame_count = r->relative_frame_count;

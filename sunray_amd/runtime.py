@@ -47,6 +47,16 @@ def decode_image(data):
     return out
 
 
+def decode_image_rgba8(data):
+    """image::load_from_memory(..).to_rgba8() (lib.rs:281-283): PNG (8- and 16-bit) / JPEG -> (h, w, 4) uint8."""
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+    w, h = C.c_uint32(), C.c_uint32()
+    check(lib().sr_decode_image_rgba8(buf, C.c_size_t(len(data)), C.byref(w), C.byref(h), None, C.c_size_t(0)))
+    out = np.zeros((h.value, w.value, 4), dtype=np.uint8)
+    check(lib().sr_decode_image_rgba8(buf, C.c_size_t(len(data)), C.byref(w), C.byref(h), _p(out), C.c_size_t(out.size)))
+    return out
+
+
 def emissive_triangles_from_mesh(vertices, indices, material):
     v = np.ascontiguousarray(vertices, dtype=abi.VERTEX)
     i = np.ascontiguousarray(indices, dtype=np.uint32)
@@ -468,6 +478,13 @@ class Renderer:
 
     def add_resize_callback(self, fn):
         check(lib().sr_renderer_add_resize_callback(self._h, self._keep(self._RESIZE_CB(lambda _u, w, h: fn((w, h)))), None))
+
+    def set_blue_noise(self, rgba8):
+        """Replaces the built-in noise texture (lib.rs:281-309): (h, w, 4) uint8, e.g. decode_image_rgba8 of the crate's PNG."""
+        a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] != 4:
+            raise ValueError("set_blue_noise: expected (h, w, 4) uint8")
+        check(lib().sr_renderer_set_blue_noise(self._h, _p(a), C.c_uint32(a.shape[1]), C.c_uint32(a.shape[0])))
 
     def load_mesh(self, key, vertices, indices, material):
         v = np.ascontiguousarray(vertices, dtype=abi.VERTEX)

@@ -31,6 +31,8 @@ int main(int argc, char** argv) {
         if (sr_decode_image(m.data(), m.size(), &w, &h, &c, nullptr, 0) == 0 && (size_t)w * h * c <= out.size()) {
             if (sr_decode_image(m.data(), m.size(), &w, &h, &c, out.data(), out.size()) == 0) ok++;
         }
+        if (sr_decode_image_rgba8(m.data(), m.size(), &w, &h, nullptr, 0) == 0 && (size_t)w * h * 4 <= out.size())      // + 16-bit PNG
+            (void)sr_decode_image_rgba8(m.data(), m.size(), &w, &h, out.data(), out.size());
     }
     printf("%s: %u iterations, %u decoded\n", argv[1], iters, ok);
     return 0;

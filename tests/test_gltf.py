@@ -205,6 +205,84 @@ def test_png_decoder_against_reference_decoder(tmp_path):
     assert (rt.gltf_parse(str(tmp_path / "p26.glb"))["images"][0][..., 0] == idx4 * 17).all()
 
 
+def test_png_16_bit_and_transparent_colour_to_rgba8(tmp_path):
+    """sr_decode_image_rgba8 = image::load_from_memory(..).to_rgba8() (lib.rs:281-283; the reference's blue-noise asset is a
+    16-bit greyscale PNG): 16-bit samples narrow to (v + 128) / 257, grey replicates, missing alpha is 255, and a tRNS chunk
+    of a greyscale / truecolour image becomes alpha 0 exactly where the pixel equals its colour at the file's bit depth.
+    The glTF texture path keeps refusing 16 bits, as the reference does (image/mod.rs:102-107)."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(21)
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xFFFFFFFF)
+
+    def raw_png(w, h, depth, ctype, rows, extra=b"", ft=0):
+        c = {0: 1, 2: 3, 4: 2, 6: 4}[ctype]
+        bpp = max(c * depth // 8, 1)
+        out, prev = b"", bytes(len(rows[0]))
+        for y, r in enumerate(rows):
+            f = ft if ft is not None else (y % 3)
+            if f == 0:
+                enc = r
+            elif f == 1:
+                enc = bytes((r[i] - (r[i - bpp] if i >= bpp else 0)) & 255 for i in range(len(r)))
+            else:
+                enc = bytes((r[i] - prev[i]) & 255 for i in range(len(r)))
+            out += bytes([f]) + enc
+            prev = r
+        return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + extra + chunk(b"IDAT", zlib.compress(out)) + chunk(b"IEND", b"")
+
+    def narrow(v):
+        return ((v.astype(np.uint32) + 128) // 257).astype(np.uint8)
+    h, w = 7, 9
+    for ctype, c in ((0, 1), (4, 2), (2, 3), (6, 4)):
+        v = rng.integers(0, 65536, size=(h, w, c), dtype=np.uint16)
+        v[0, 0] = 65535; v[0, 1] = 0; v[0, 2] = 128; v[0, 3] = 129; v[0, 4] = 65407; v[0, 5] = 65408     # rounding boundaries
+        rows = [v[y].astype(">u2").tobytes() for y in range(h)]
+        n8 = narrow(v)
+        want = np.full((h, w, 4), 255, dtype=np.uint8)
+        if c <= 2:
+            want[..., :3] = n8[..., :1]
+        else:
+            want[..., :3] = n8[..., :3]
+        if c in (2, 4):
+            want[..., 3] = n8[..., c - 1]
+        for ft in (0, 1, None):
+            got = rt.decode_image_rgba8(raw_png(w, h, 16, ctype, rows, ft=ft))
+            assert got.shape == want.shape and (got == want).all(), (ctype, ft)
+        with pytest.raises(rt.SunrayError):
+            rt.decode_image(raw_png(w, h, 16, ctype, rows))            # the texture path: R16* -> todo!() in the reference
+    # transparent colour: 16-bit grey, 8-bit grey, 2-bit grey, 8-bit truecolour, 16-bit truecolour
+    g16 = rng.integers(0, 4, size=(h, w), dtype=np.uint16) * 300 + 5
+    got = rt.decode_image_rgba8(raw_png(w, h, 16, 0, [g16[y].astype(">u2").tobytes() for y in range(h)], chunk(b"tRNS", struct.pack(">H", 305))))
+    assert (got[..., 3] == np.where(g16 == 305, 0, 255)).all() and (got[..., 0] == narrow(g16)).all() and (g16 == 305).any()
+    g8 = rng.integers(0, 5, size=(h, w), dtype=np.uint8) * 50
+    png = raw_png(w, h, 8, 0, [g8[y].tobytes() for y in range(h)], chunk(b"tRNS", struct.pack(">H", 100)))
+    got = rt.decode_image(png)
+    assert got.shape == (h, w, 2) and (got[..., 0] == g8).all() and (got[..., 1] == np.where(g8 == 100, 0, 255)).all()
+    assert (rt.decode_image_rgba8(png)[..., 3] == got[..., 1]).all()
+    g2 = rng.integers(0, 4, size=(3, 8), dtype=np.uint8)
+    rows2 = [bytes(((g2[y, 0::4] << 6) | (g2[y, 1::4] << 4) | (g2[y, 2::4] << 2) | g2[y, 3::4]).astype(np.uint8)) for y in range(3)]
+    got = rt.decode_image(raw_png(8, 3, 2, 0, rows2, chunk(b"tRNS", struct.pack(">H", 2))))
+    assert got.shape == (3, 8, 2) and (got[..., 0] == g2 * 85).all() and (got[..., 1] == np.where(g2 == 2, 0, 255)).all()
+    c8 = rng.integers(0, 2, size=(h, w, 3), dtype=np.uint8) * 200
+    got = rt.decode_image(raw_png(w, h, 8, 2, [c8[y].tobytes() for y in range(h)], chunk(b"tRNS", struct.pack(">HHH", 200, 0, 200))))
+    key = (c8 == np.array([200, 0, 200], dtype=np.uint8)).all(axis=2)
+    assert got.shape == (h, w, 4) and (got[..., :3] == c8).all() and (got[..., 3] == np.where(key, 0, 255)).all() and key.any()
+    c16 = rng.integers(0, 2, size=(h, w, 3), dtype=np.uint16) * 40000
+    got = rt.decode_image_rgba8(raw_png(w, h, 16, 2, [c16[y].astype(">u2").tobytes() for y in range(h)], chunk(b"tRNS", struct.pack(">HHH", 40000, 40000, 0))))
+    key = (c16 == np.array([40000, 40000, 0], dtype=np.uint16)).all(axis=2)
+    assert (got[..., :3] == narrow(c16)).all() and (got[..., 3] == np.where(key, 0, 255)).all() and key.any()
+    # 8-bit inputs and JPEG go through unchanged but widened
+    rgb = rng.integers(0, 256, size=(5, 6, 3), dtype=np.uint8)
+    got = rt.decode_image_rgba8(gltf_util.encode_png(rgb))
+    assert (got[..., :3] == rgb).all() and (got[..., 3] == 255).all()
+    jpg = open(os.path.join(os.path.dirname(__file__), "golden", "tiny_gray.jpg"), "rb").read()
+    a, b = rt.decode_image(jpg), rt.decode_image_rgba8(jpg)
+    assert a.shape[2] == 1 and (b[..., 0] == a[..., 0]).all() and (b[..., 1] == b[..., 0]).all() and (b[..., 3] == 255).all()
+
+
 def test_jpeg_decoder_against_libjpeg(tmp_path):
     """JPEG textures (what `gltf::import` decodes through the image crate): baseline and progressive, greyscale, 4:4:4 / 4:2:2 /
     4:2:0 chroma, optimised Huffman tables, restart intervals, odd extents — against Pillow's libjpeg within the margin JPEG

@@ -586,6 +586,34 @@ def test_renderer_render_to_host_memory_equals_oracle(rt, oracle):
     r.close()
 
 
+def test_renderer_with_a_host_supplied_noise_texture(rt, oracle):
+    """lib.rs:281-309: the reference embeds a 16-bit greyscale PNG and uploads its to_rgba8() form. A host that owns that asset
+    decodes it (sr_decode_image_rgba8) and hands it to the renderer; here a synthetic 16-bit PNG of another extent stands in."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(77)
+    v = rng.integers(0, 65536, size=(48, 64), dtype=np.uint16)
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xFFFFFFFF)
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 64, 48, 16, 0, 0, 0, 0)) +
+           chunk(b"IDAT", zlib.compress(b"".join(b"\x00" + v[y].astype(">u2").tobytes() for y in range(48)))) + chunk(b"IEND", b""))
+    noise = rt.decode_image_rgba8(png)
+    assert noise.shape == (48, 64, 4) and (noise[..., 0] == ((v.astype(np.uint32) + 128) // 257)).all() and (noise[..., 3] == 255).all()
+    desc = scenes.cornell_glass_mirror()          # specular first bounces: the passes sample the texture (ray_gen_final.slang:44-50,397-399)
+    W, H = 72, 56
+    r = rt.Renderer((W, H))
+    r.set_blue_noise(noise)
+    for m in desc.meshes:
+        r.load_mesh(m.key, m.vertices, m.indices, m.material)
+    img = r.render_to_host_memory((desc.camera_pos, desc.camera_target, desc.fov_y), desc.instances)
+    of, _ = _oracle_render_to_host_memory(oracle, desc, W, H, [desc.instances] * 16, noise)
+    assert_bits_equal(of.output, img.view(np.uint32).reshape(-1), "render_to_host_memory with a host-supplied noise texture")
+    with pytest.raises(rt.SunrayError):
+        r.set_blue_noise(np.zeros((0, 4, 4), dtype=np.uint8))
+    r.close()
+
+
 def test_renderer_resize_and_instance_change(rt, oracle):
     desc = scenes.cornell_box()
     noise = rt.default_noise_texture()
