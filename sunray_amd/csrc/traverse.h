@@ -128,12 +128,11 @@ SRD bool intersect_tri(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax, 
 // box test only, so the slab of an axis-parallel ray is (-huge, +huge) inside, same-signed outside and [0, huge] on a
 // face — no 0*inf, no NaN — while the triangle test keeps the true direction. The far side is inflated (Ize 2013).
 struct RaySetup {
-    f3 o, inv;         // inv carries the direction signs (box_dir keeps the sign of a zero component)
+    f3 inv;            // carries the direction signs (box_dir keeps the sign of a zero component)
 };
 SRD float box_dir(float d) { return fabsf(d) >= 7.888609e-31f ? d : copysignf(7.888609e-31f, d); }   // 2^-100
 SRD RaySetup ray_setup(f3 o, f3 d) {
     RaySetup r;
-    r.o = o;
     r.inv = mk3(1.0f / box_dir(d.x), 1.0f / box_dir(d.y), 1.0f / box_dir(d.z));
     return r;
 }
@@ -239,7 +238,7 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                     if (takes) {
                         node = stack_base[d_sb * stride + (dl - (int)lane)];
                         o = mk3(ox, oy, oz); d = mk3(dx, dy, dz); tmin = d_tmin; tmax = d_tmax; cull = d_cull; root = d_root;
-                        rs.o = o; rs.inv = mk3(ix, iy, iz);
+                        rs.inv = mk3(ix, iy, iz);
                         t_lo = fminf(tmin, 0.0f) - fabsf(tmin);
                         best_t = tmax; best_gid = 0xFFFFFFFFu;
                         sp = 0; sb = 0;
@@ -267,7 +266,7 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                 p.nz = sgz ? HZ : LZ; p.fz = sgz ? LZ : HZ;
                 p.ax = __uint_as_float((ex & 0xFFu) << 23) * rs.inv.x; p.ay = __uint_as_float(((ex >> 8) & 0xFFu) << 23) * rs.inv.y;
                 p.az = __uint_as_float(((ex >> 16) & 0xFFu) << 23) * rs.inv.z;
-                p.bx = (h0.x - rs.o.x) * rs.inv.x; p.by = (h0.y - rs.o.y) * rs.inv.y; p.bz = (h0.z - rs.o.z) * rs.inv.z;
+                p.bx = (h0.x - o.x) * rs.inv.x; p.by = (h0.y - o.y) * rs.inv.y; p.bz = (h0.z - o.z) * rs.inv.z;
                 float n0, n1, n2, n3;
                 const bool b0 = child_hit<0>(p, t_lo, cull, n0);
                 const bool b1 = child_hit<1>(p, t_lo, cull, n1);
