@@ -274,7 +274,15 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                 const bool b3 = child_hit<3>(p, t_lo, cull, n3);
                 uint32_t k0, k1, k2, k3;
                 if (ANY) {
-                    k0 = b0 ? 0u : 0xFFFFFFFFu; k1 = b1 ? 1u : 0xFFFFFFFFu; k2 = b2 ? 2u : 0xFFFFFFFFu; k3 = b3 ? 3u : 0xFFFFFFFFu;
+                    // Existence queries visit the hit child whose entry point is FARTHEST first (closest-hit queries need the
+                    // nearest first, for culling). No order changes their answer; this one leaves the near, dense subtrees on
+                    // the stack, where idle lanes can take them over, and lets the lane itself finish the far, mostly empty
+                    // ones — measured on the bench frame: slot order 1.86 ms, nearest entry first 1.98, nearest exit first
+                    // 1.99, longest way through the box first 1.89, farthest exit first 1.81, farthest entry first 1.81.
+                    k0 = b0 ? (((0x7F7FFFFFu - __float_as_uint(fminf(fmaxf(n0, 0.0f), 3.0e38f))) & ~3u) | 0u) : 0xFFFFFFFFu;
+                    k1 = b1 ? (((0x7F7FFFFFu - __float_as_uint(fminf(fmaxf(n1, 0.0f), 3.0e38f))) & ~3u) | 1u) : 0xFFFFFFFFu;
+                    k2 = b2 ? (((0x7F7FFFFFu - __float_as_uint(fminf(fmaxf(n2, 0.0f), 3.0e38f))) & ~3u) | 2u) : 0xFFFFFFFFu;
+                    k3 = b3 ? (((0x7F7FFFFFu - __float_as_uint(fminf(fmaxf(n3, 0.0f), 3.0e38f))) & ~3u) | 3u) : 0xFFFFFFFFu;
                 } else {
                     k0 = b0 ? ((__float_as_uint(fmaxf(n0, 0.0f)) & ~3u) | 0u) : 0xFFFFFFFFu;
                     k1 = b1 ? ((__float_as_uint(fmaxf(n1, 0.0f)) & ~3u) | 1u) : 0xFFFFFFFFu;
