@@ -279,10 +279,12 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                     // the stack, where idle lanes can take them over, and lets the lane itself finish the far, mostly empty
                     // ones — measured on the bench frame: slot order 1.86 ms, nearest entry first 1.98, nearest exit first
                     // 1.99, longest way through the box first 1.89, farthest exit first 1.81, farthest entry first 1.81.
-                    k0 = b0 ? (((0x7F7FFFFFu - __float_as_uint(fminf(fmaxf(n0, 0.0f), 3.0e38f))) & ~3u) | 0u) : 0xFFFFFFFFu;
-                    k1 = b1 ? (((0x7F7FFFFFu - __float_as_uint(fminf(fmaxf(n1, 0.0f), 3.0e38f))) & ~3u) | 1u) : 0xFFFFFFFFu;
-                    k2 = b2 ? (((0x7F7FFFFFu - __float_as_uint(fminf(fmaxf(n2, 0.0f), 3.0e38f))) & ~3u) | 2u) : 0xFFFFFFFFu;
-                    k3 = b3 ? (((0x7F7FFFFFu - __float_as_uint(fminf(fmaxf(n3, 0.0f), 3.0e38f))) & ~3u) | 3u) : 0xFFFFFFFFu;
+                    // (the order is a heuristic: the bits of a non-negative float, inverted, order it descending; an entry
+                    // point behind the origin gets some rank of its own. Sign bit cleared: every key stays below the "missed" one.)
+                    k0 = b0 ? ((~__float_as_uint(n0) & 0x7FFFFFFCu) | 0u) : 0xFFFFFFFFu;
+                    k1 = b1 ? ((~__float_as_uint(n1) & 0x7FFFFFFCu) | 1u) : 0xFFFFFFFFu;
+                    k2 = b2 ? ((~__float_as_uint(n2) & 0x7FFFFFFCu) | 2u) : 0xFFFFFFFFu;
+                    k3 = b3 ? ((~__float_as_uint(n3) & 0x7FFFFFFCu) | 3u) : 0xFFFFFFFFu;
                 } else {
                     k0 = b0 ? ((__float_as_uint(fmaxf(n0, 0.0f)) & ~3u) | 0u) : 0xFFFFFFFFu;
                     k1 = b1 ? ((__float_as_uint(fmaxf(n1, 0.0f)) & ~3u) | 1u) : 0xFFFFFFFFu;
