@@ -89,8 +89,9 @@ SRD float exp_pinned(float x) {
     float y = fmaf(p, z, r) + 1.0f;
     int k = (int)kf;
     int k1 = k / 2, k2 = k - k1;
-    y = y * __uint_as_float((uint32_t)(k1 + 127) << 23);
-    return y * __uint_as_float((uint32_t)(k2 + 127) << 23);
+    // two exact scalings by a power of two, as the oracle's two multiplications (each rounds like the product would, also
+    // into the denormal range): v_ldexp_f32 instead of building 2^k and multiplying
+    return ldexpf(ldexpf(y, k1), k2);
 }
 
 // natural log pinned like sin/cos/exp (Cephes logf, polynomial as explicit fma); pow(x, y) = exp(y * log(x))
