@@ -232,6 +232,15 @@ typedef struct SrRtParams {
     uint32_t blue_noise_w, blue_noise_h;
     SrReservoir* reservoirs[2];      /* device, W*H each; ping-pong by frame_count & 1 (rt_utils.slang:241-242) */
     SrReservoirGI* reservoirs_gi[2]; /* device, W*H each */
+    /* Primary-hit hand-off (optional, device, W*H records, caller-owned like the G-buffer images). Both reference passes
+     * start with the SAME query: ray_gen_final.slang:80 at bounce 0 is ray_gen_ris.slang:75 at virtual bounce 0 (same
+     * pixel, same matrices, same TLAS), and TraceRay is a pure function of its arguments. With a buffer here sr_trace_ris
+     * stores that query's 32-byte RayPayload (T8, closest_hit / miss applied) per pixel and sr_trace_final, enqueued
+     * after it for the same frame, reads it back instead of traversing and shading again — same bits, one traversal
+     * fewer per pixel (counted in SrRayCounters.reused_primary_hits, not in closest_queries). NULL: sr_trace_final traces
+     * the query itself. Ignored when config.enable_restir == 0 (no RIS pass ran) or config.virtual_bounces == 0. Part of
+     * the per-frame image set: double-buffer it with the G-buffer when two frames are in flight. */
+    SrRayPayload* primary_payload;
     uint32_t frame_count;            /* relative_frame_count (lib.rs:1355,1386) */
     uint32_t use_srgb;               /* carried, unused by the shaders */
     uint32_t width, height;          /* trace_extent[0], [1]; also the image size */
@@ -245,10 +254,13 @@ typedef struct SrRtParams {
 
 /* Ray counters accumulated by the kernels (rays are counted, not estimated). */
 typedef struct SrRayCounters {
-    uint64_t closest_queries; /* TraceRay(RAY_FLAG_NONE) issued            */
-    uint64_t any_queries;     /* TraceRay(ACCEPT_FIRST_HIT|SKIP_CLOSEST) issued */
+    uint64_t closest_queries; /* TraceRay(RAY_FLAG_NONE) traversed         */
+    uint64_t any_queries;     /* TraceRay(ACCEPT_FIRST_HIT|SKIP_CLOSEST) traversed */
     uint64_t boxes_tested;    /* child boxes tested (32 B each), only in the instrumented build */
     uint64_t tris_tested;     /* triangle records tested (48 B each), only in the instrumented build */
+    uint64_t reused_primary_hits; /* TraceRay(RAY_FLAG_NONE) calls of the reference's final pass answered from
+                                     SrRtParams.primary_payload without a traversal: the reference issues
+                                     closest_queries + reused_primary_hits closest-hit queries */
 } SrRayCounters;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -623,7 +635,7 @@ static_assert(sizeof(SrMatrices) == 256, "T6");
 static_assert(sizeof(SrReservoir) == 48 && sizeof(SrReservoirGI) == 48, "T7");
 static_assert(sizeof(SrRayPayload) == 32, "T8");
 static_assert(sizeof(SrRay) == 32 && sizeof(SrHit) == 16, "ray/hit");
-static_assert(sizeof(SrTraceConfig) == 40 && sizeof(SrRtParams) == 176, "T9");
+static_assert(sizeof(SrTraceConfig) == 40 && sizeof(SrRtParams) == 184, "T9");
 static_assert(sizeof(SrPostParams) == 104, "post params");
 #endif
 

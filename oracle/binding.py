@@ -224,6 +224,7 @@ class OracleScene:
         p.blue_noise_h, p.blue_noise_w = frame.blue_noise.shape[:2]
         p.reservoirs[0], p.reservoirs[1] = frame.reservoirs[0].ctypes.data, frame.reservoirs[1].ctypes.data
         p.reservoirs_gi[0], p.reservoirs_gi[1] = frame.reservoirs_gi[0].ctypes.data, frame.reservoirs_gi[1].ctypes.data
+        p.primary_payload = frame.primary.ctypes.data     # written by trace_ris for the tests, never read by trace_final
         p.frame_count = frame_count
         p.use_srgb = 0
         p.width, p.height = frame.width, frame.height
@@ -268,6 +269,7 @@ class HostFrame:
         self.accum = [np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)]
         self.denoise = [np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)]
         self.output = np.zeros(n, dtype=np.uint32)
+        self.primary = np.zeros(n, dtype=abi.RAY_PAYLOAD)     # camera-ray payloads as trace_ris sees them (test aid)
 
 
 def post_chain(frame, frame_count, exposure=1.0, denoise_passes=4, stages=("temporal", "denoise", "tonemap")):

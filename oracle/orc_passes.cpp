@@ -108,6 +108,9 @@ void ris_pixel(Ctx& cx, uint32_t px, uint32_t py) {
 
     for (uint32_t virtual_bounce = 0; virtual_bounce < pc.config.virtual_bounces; virtual_bounce++) {  // :69
         cx.trace(rayOrigin, rayDir, 0.001f, 10000.0f, prd);          // :70-75
+        // not in the reference: the camera ray's payload, exposed so that tests can check what the HIP path's RIS pass
+        // hands to its final pass (SrRtParams.primary_payload). The oracle's own final pass never reads it.
+        if (virtual_bounce == 0 && pc.primary_payload) pc.primary_payload[pix] = prd;
         if (prd.dist < 0.0f) break;                                  // :77-79
         hitPos = rayOrigin + rayDir * prd.dist;                      // :81
         hit_normal = unpack_normal(prd.normal_packed);

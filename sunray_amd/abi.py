@@ -66,7 +66,7 @@ class SrRtParams(C.Structure):  # T9
                 ("normal_img", C.c_void_p), ("diffuse_img", C.c_void_p), ("motion_vec_img", C.c_void_p),
                 ("matrices", C.POINTER(SrMatrices)), ("blue_noise_tex", C.c_void_p),
                 ("blue_noise_w", C.c_uint32), ("blue_noise_h", C.c_uint32),
-                ("reservoirs", C.c_void_p * 2), ("reservoirs_gi", C.c_void_p * 2),
+                ("reservoirs", C.c_void_p * 2), ("reservoirs_gi", C.c_void_p * 2), ("primary_payload", C.c_void_p),
                 ("frame_count", C.c_uint32), ("use_srgb", C.c_uint32),
                 ("width", C.c_uint32), ("height", C.c_uint32), ("tile_y0", C.c_uint32), ("tile_h", C.c_uint32),
                 ("tile_x0", C.c_uint32), ("tile_w", C.c_uint32), ("config", SrTraceConfig)]
@@ -96,7 +96,7 @@ def post_params(frame, frame_count, ptr, exposure=1.0, denoise_passes=4):
 
 class SrRayCounters(C.Structure):
     _fields_ = [("closest_queries", C.c_uint64), ("any_queries", C.c_uint64),
-                ("boxes_tested", C.c_uint64), ("tris_tested", C.c_uint64)]
+                ("boxes_tested", C.c_uint64), ("tris_tested", C.c_uint64), ("reused_primary_hits", C.c_uint64)]
 
 
 class SrBvhStats(C.Structure):

@@ -69,7 +69,7 @@ struct DeviceBuffer {
 
 }  // namespace
 
-constexpr size_t kQueueHeadOffset = 256;   // d_misc: [0,32) ray counters, [256, 256 + 16 * kQueueHeads) queue heads
+constexpr size_t kQueueHeadOffset = 256;   // d_misc: [0,40) ray counters, [256, 256 + 16 * kQueueHeads) queue heads
 constexpr uint32_t kQueueHeads = 64;
 
 struct SrScene {
@@ -862,6 +862,8 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
     a.blue_noise_tex = p->blue_noise_tex; a.blue_noise_w = p->blue_noise_w; a.blue_noise_h = p->blue_noise_h;
     a.reservoirs[0] = p->reservoirs[0]; a.reservoirs[1] = p->reservoirs[1];
     a.reservoirs_gi[0] = p->reservoirs_gi[0]; a.reservoirs_gi[1] = p->reservoirs_gi[1];
+    // primary-hit hand-off: written by the RIS pass at virtual bounce 0, read by the final pass at bounce 0 — only where a RIS pass ran
+    a.primary_payload = (need_restir && p->config.virtual_bounces > 0) ? p->primary_payload : nullptr;
     a.frame_count = p->frame_count;
     a.width = p->width; a.height = p->height;
     a.y0 = y0; a.y1 = y1; a.x0 = x0; a.x1 = x1;
@@ -983,7 +985,7 @@ int sr_scene_reset_counters(SrScene* s, void* stream) {
     if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_reset_counters: scene is null");
     int rc = bind_device(s);
     if (rc != SR_OK) return rc;
-    HIP_TRY(hipMemsetAsync(s->d_misc.p, 0, 32, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(s->d_misc.p, 0, 40, (hipStream_t)stream));
     return SR_OK;
 }
 
@@ -991,10 +993,10 @@ int sr_scene_read_counters(SrScene* s, void* stream, SrRayCounters* out) {
     if (!s || !out) return fail(SR_ERR_INVALID_ARG, "sr_scene_read_counters: null argument");
     int rc = bind_device(s);
     if (rc != SR_OK) return rc;
-    unsigned long long v[4];
+    unsigned long long v[5];
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     HIP_TRY(hipMemcpy(v, s->d_misc.p, sizeof(v), hipMemcpyDeviceToHost));
-    out->closest_queries = v[0]; out->any_queries = v[1]; out->boxes_tested = v[2]; out->tris_tested = v[3];
+    out->closest_queries = v[0]; out->any_queries = v[1]; out->boxes_tested = v[2]; out->tris_tested = v[3]; out->reused_primary_hits = v[4];
     return SR_OK;
 }
 

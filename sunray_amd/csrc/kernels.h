@@ -20,6 +20,9 @@ struct PassArgs {
     uint32_t blue_noise_w, blue_noise_h;
     SrReservoir* reservoirs[2];
     SrReservoirGI* reservoirs_gi[2];
+    // primary-hit hand-off (SrRtParams.primary_payload): the RIS pass stores the shaded payload of its virtual bounce 0,
+    // the final pass starts from it instead of tracing the same camera ray again; null = the final pass traces it
+    SrRayPayload* primary_payload;
     uint32_t frame_count;
     uint32_t width, height;
     uint32_t y0, y1;              // rows [y0, y1) and

@@ -116,6 +116,7 @@ struct PixelCtx {
     int* stack;
     uint32_t n_closest, n_any;
     TravStats st;
+    uint32_t n_reused = 0;   // closest-hit queries of the reference answered from the primary-hit hand-off instead of a traversal
 };
 
 template <int V>
@@ -173,6 +174,22 @@ SRD void store48(T* p, const T& v) {
     float4* d = reinterpret_cast<float4*>(p);
     const float4* s = reinterpret_cast<const float4*>(&v);
     d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+
+// 32-byte RayPayload records of the primary-hit hand-off: two 16-byte accesses per lane
+SRD void store_payload(SrRayPayload* p, const Payload& v) {
+    float4* d = reinterpret_cast<float4*>(p);
+    d[0] = make_float4(v.emission.x, v.emission.y, v.emission.z, v.dist);
+    d[1] = make_float4(__uint_as_float(v.albedo_packed), __uint_as_float(v.normal_packed), __uint_as_float(v.material_info), __uint_as_float(v.transmission_ior_packed));
+}
+SRD Payload load_payload(const SrRayPayload* p) {
+    const float4* s = reinterpret_cast<const float4*>(p);
+    const float4 a = s[0], b = s[1];
+    Payload v;
+    v.emission = mk3(a.x, a.y, a.z); v.dist = a.w;
+    v.albedo_packed = __float_as_uint(b.x); v.normal_packed = __float_as_uint(b.y);
+    v.material_info = __float_as_uint(b.z); v.transmission_ior_packed = __float_as_uint(b.w);
+    return v;
 }
 
 SRD f3 light_emission(const DevScene& sc, uint32_t indirection_idx) { return ld3(sc.lights[indirection_idx].emission); }
@@ -376,6 +393,8 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void ris_kernel(const PassA
 
         for (uint32_t vb = 0; vb < a.cfg.virtual_bounces; vb++) {
             prd = trace_closest_shaded<V>(cx, rayOrigin, rayDir, 0.001f, 10000.0f);
+            // the camera ray's payload, for the final pass: ray_gen_final.slang:80 at bounce 0 is this very query
+            if (vb == 0u && a.primary_payload) store_payload(a.primary_payload + pix, prd);
             if (prd.dist < 0.0f) break;
             hitPos = rayOrigin + rayDir * prd.dist;
             hit_normal = unpack_normal(prd.normal_packed);
@@ -628,12 +647,16 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
     bool in_loop = active;
     for (int bounce = 0; bounce < BOUNCES; bounce++) {                                 // :74
         if (__builtin_amdgcn_ballot_w64(in_loop) == 0ull) break;
-        ws_query<V, false>(cx, in_loop, rayOrigin, rayDir, 0.001f, 10000.0f, h);
+        // bounce 0 is the query the RIS pass answered for this pixel a moment ago (same camera ray, same structure): with the
+        // hand-off buffer the payload is read back instead of traversed and shaded again (launch-uniform condition)
+        const bool reuse_primary = bounce == 0 && a.primary_payload != nullptr;
+        if (!reuse_primary) ws_query<V, false>(cx, in_loop, rayOrigin, rayDir, 0.001f, 10000.0f, h);
         bool do_restir = false, do_nee = false, do_bounce = false;
         f3 hit_normal = splat(0.0f), hit_albedo = splat(0.0f), hitPos = splat(0.0f), V_view = splat(0.0f);
         float roughness = 0.5f, metallic = 0.0f;
         if (in_loop) {
-            prd = shade_hit<(V & 2) != 0>(sc, h);
+            if (reuse_primary) { prd = load_payload(a.primary_payload + pix); cx.n_reused++; }
+            else prd = shade_hit<(V & 2) != 0>(sc, h);
             if (prd.dist < 0.0f) in_loop = false;                                      // :82-84
             else {
                 hit_normal = unpack_normal(prd.normal_packed);
@@ -925,6 +948,7 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
                              (a.cfg.count_cols == 0u || (px - a.cfg.count_x0) < a.cfg.count_cols);       // and column
         flush_counter(sc.counters + 0, counted ? cx.n_closest : 0u);
         flush_counter(sc.counters + 1, counted ? cx.n_any : 0u);
+        flush_counter(sc.counters + 4, counted ? cx.n_reused : 0u);
         if (V & 1) { flush_counter(sc.counters + 2, counted ? cx.st.boxes : 0u); flush_counter(sc.counters + 3, counted ? cx.st.tris : 0u); }
     }
 }

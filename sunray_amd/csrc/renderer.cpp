@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <array>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -29,6 +30,8 @@ struct SrRenderer {
     SrReservoirGI* reservoirs_gi[2] = {nullptr, nullptr};
     uint32_t *accum[2] = {nullptr, nullptr}, *denoise[2] = {nullptr, nullptr};
     uint32_t* output[2] = {nullptr, nullptr};
+    SrRayPayload* primary[2] = {nullptr, nullptr};   // primary-hit hand-off RIS -> final (SrRtParams.primary_payload), part of the per-frame set
+    int primary_reuse = 1;                           // SR_PRIMARY_REUSE=0 in the environment: the final pass traces its camera ray itself (A/B)
     hipStream_t s_ris = nullptr, s_final = nullptr;
     hipEvent_t ev_in = nullptr, ev_ris[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     int last_set = 0;
@@ -72,9 +75,9 @@ int rfail(int code, const std::string& msg) { return srh::set_error(code, msg); 
 void free_images(SrRenderer* r) {
     void* ptrs[] = {r->raw_color[0], r->raw_color[1], r->depth[0], r->depth[1], r->normal[0], r->normal[1], r->diffuse[0], r->diffuse[1],
                     r->motion[0], r->motion[1], r->reservoirs[0], r->reservoirs[1], r->reservoirs_gi[0], r->reservoirs_gi[1], r->accum[0],
-                    r->accum[1], r->denoise[0], r->denoise[1], r->output[0], r->output[1]};
+                    r->accum[1], r->denoise[0], r->denoise[1], r->output[0], r->output[1], r->primary[0], r->primary[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (int k = 0; k < 2; k++) { r->raw_color[k] = nullptr; r->depth[k] = nullptr; r->normal[k] = r->diffuse[k] = r->motion[k] = nullptr; r->output[k] = nullptr; }
+    for (int k = 0; k < 2; k++) { r->primary[k] = nullptr; r->raw_color[k] = nullptr; r->depth[k] = nullptr; r->normal[k] = r->diffuse[k] = r->motion[k] = nullptr; r->output[k] = nullptr; }
     r->reservoirs[0] = r->reservoirs[1] = nullptr; r->reservoirs_gi[0] = r->reservoirs_gi[1] = nullptr;
     r->accum[0] = r->accum[1] = r->denoise[0] = r->denoise[1] = nullptr;
 }
@@ -91,7 +94,8 @@ int alloc_images(SrRenderer* r, uint32_t w, uint32_t h) {
     int rc;
     for (int i = 0; i < 2; i++)
         if ((rc = alloc_zero(&r->raw_color[i], n * 4)) || (rc = alloc_zero(&r->depth[i], n)) || (rc = alloc_zero(&r->normal[i], n)) ||
-            (rc = alloc_zero(&r->diffuse[i], n)) || (rc = alloc_zero(&r->motion[i], n)) || (rc = alloc_zero(&r->output[i], n))) return rc;
+            (rc = alloc_zero(&r->diffuse[i], n)) || (rc = alloc_zero(&r->motion[i], n)) || (rc = alloc_zero(&r->output[i], n)) ||
+            (r->primary_reuse && (rc = alloc_zero(&r->primary[i], n)))) return rc;
     for (int i = 0; i < 2; i++)
         if ((rc = alloc_zero(&r->reservoirs[i], n)) || (rc = alloc_zero(&r->reservoirs_gi[i], n)) ||
             (rc = alloc_zero(&r->accum[i], n)) || (rc = alloc_zero(&r->denoise[i], n))) return rc;
@@ -127,6 +131,7 @@ int sr_renderer_create(int device, uint32_t width, uint32_t height, SrRenderer**
     r->device = device;
     memset(r->prev_view_proj, 0, sizeof(r->prev_view_proj));
     sr_trace_config_default(&r->config);
+    if (const char* ev = getenv("SR_PRIMARY_REUSE")) r->primary_reuse = atoi(ev) != 0;
     int rc = sr_scene_create(device, &r->scene);
     if (rc != SR_OK) { delete r; return rc; }
     if ((rc = alloc_images(r, width, height)) != SR_OK) { free_images(r); sr_scene_destroy(r->scene); delete r; return rc; }
@@ -285,6 +290,7 @@ int sr_renderer_render(SrRenderer* r, const float cam_pos[3], const float cam_ta
     p.blue_noise_tex = r->blue_noise; p.blue_noise_w = r->noise_w; p.blue_noise_h = r->noise_h;
     p.reservoirs[0] = r->reservoirs[0]; p.reservoirs[1] = r->reservoirs[1];
     p.reservoirs_gi[0] = r->reservoirs_gi[0]; p.reservoirs_gi[1] = r->reservoirs_gi[1];
+    p.primary_payload = r->primary[k];
     p.frame_count = r->relative_frame_count;
     p.width = r->width; p.height = r->height;
     p.config = r->config;

@@ -83,7 +83,7 @@ struct DevScene {
     const DevInstance* instances;
     const DevLight* lights;        // [num_lights]
     const uint32_t* slot_of_gid;   // global triangle index -> leaf-order slot (sr_shade_closest_hit only)
-    unsigned long long* counters;  // [0]=closest queries [1]=any queries [2]=boxes [3]=tris
+    unsigned long long* counters;  // [0]=closest queries [1]=any queries [2]=boxes [3]=tris [4]=primary hits reused
     uint32_t num_lights;
     uint32_t n_tris;
     uint32_t n_instances;

@@ -204,6 +204,7 @@ class FramePipeline:
     G-buffer images and the current reservoir buffers and only READS the previous frame's reservoirs; the final pass
     reads the G-buffer and the current reservoirs. With the G-buffer double-buffered (two frame objects that share
     their reservoir arrays) the only orderings left are RIS(f) -> final(f), RIS(f) -> RIS(f+1) and final(f-2) -> RIS(f).
+    The primary-hit hand-off (RIS(f) writes the camera ray's payload, final(f) reads it) belongs to that double-buffered set.
     Results are those of sequential execution, bit for bit (test_frames_in_flight_equal_sequential_frames).
     Two is also the limit: a third frame in flight needs a third physical reservoir buffer, and the reference's reservoirs are
     a two-buffer ping-pong whose STALE contents are observable — a sky pixel leaves its GI reservoir unwritten
@@ -269,7 +270,9 @@ class GatherPipeline:
         a0, n = self.part.span(self.rank)
         if n > 0:
             self.part.cut(self.send[k], 0, n).copy_(self.part.cut(self.part.view(raw_color, 4), a0, n))
-        if self.part.world > 1:
+        # one rank and no process group: nothing to gather. With a process group the collective is issued even for one
+        # rank, so that a 1-GPU run exercises the same RCCL initialisation, stream ordering and image() path as N ranks.
+        if self.part.world > 1 or all_gather is not None or (dist.is_available() and dist.is_initialized()):
             fn = all_gather or (lambda out, inp: dist.all_gather_into_tensor(out, inp, async_op=True))
             self.work[k] = fn(self.recv[k], self.send[k])
         else:

@@ -114,7 +114,10 @@ def decode_node(node):
 class DeviceFrame:
     """Frame buffers in HBM with the layouts of SrRtParams (torch tensors on one device)."""
 
-    def __init__(self, width, height, blue_noise, device="cuda:0"):
+    def __init__(self, width, height, blue_noise, device="cuda:0", primary=None):
+        """`primary`: allocate the primary-hit hand-off buffer (SrRtParams.primary_payload). Default: yes, unless
+        SUNRAY_PRIMARY_REUSE=0 is set in the environment (A/B switch of tests and scripts)."""
+        import os
         import torch
         self.width, self.height = width, height
         n = width * height
@@ -131,6 +134,9 @@ class DeviceFrame:
         self.accum = [z(n, dtype=torch.int32), z(n, dtype=torch.int32)]
         self.denoise = [z(n, dtype=torch.int32), z(n, dtype=torch.int32)]
         self.output = z(n, dtype=torch.int32)
+        if primary is None:
+            primary = os.environ.get("SUNRAY_PRIMARY_REUSE", "1") != "0"
+        self.primary = z(n, 8, dtype=torch.int32) if primary else None      # 32-B RayPayload of the camera ray (RIS -> final hand-off)
         bn = np.ascontiguousarray(blue_noise, dtype=np.uint8)
         self.blue_noise_shape = bn.shape[:2]
         self.blue_noise = torch.from_numpy(bn.copy()).to(self.device)
@@ -325,6 +331,8 @@ class Scene:
         p.blue_noise_h, p.blue_noise_w = frame.blue_noise_shape
         p.reservoirs[0], p.reservoirs[1] = frame.reservoirs[0].data_ptr(), frame.reservoirs[1].data_ptr()
         p.reservoirs_gi[0], p.reservoirs_gi[1] = frame.reservoirs_gi[0].data_ptr(), frame.reservoirs_gi[1].data_ptr()
+        prim = getattr(frame, "primary", None)
+        p.primary_payload = prim.data_ptr() if prim is not None else None
         p.frame_count = frame_count
         p.use_srgb = 0
         p.width, p.height = frame.width, frame.height

@@ -46,11 +46,18 @@ def assert_bits_equal(a, b, what):
     assert nd == 0, "%s: %d of %d bytes differ" % (what, nd, a.size)
 
 
-def run_both(rt, oracle, desc, W, H, frames, blue_noise, cfg=None, check_counters=True):
-    """Renders `frames` consecutive frames on GPU and oracle; asserts bitwise parity every frame."""
+def ref_closest(c):
+    """Closest-hit TraceRay calls the REFERENCE issues for what was rendered: the traversals executed plus the camera-ray
+    queries of the final pass that were answered from the RIS pass's hand-off (SrRtParams.primary_payload)."""
+    return c.closest_queries + c.reused_primary_hits
+
+
+def run_both(rt, oracle, desc, W, H, frames, blue_noise, cfg=None, check_counters=True, primary=None):
+    """Renders `frames` consecutive frames on GPU and oracle; asserts bitwise parity every frame. `primary`: with / without
+    the primary-hit hand-off buffer (None: the harness default, i.e. with)."""
     osc = oracle.OracleScene().load(desc)
     gsc = rt.Scene(0).load(desc)
-    of, gf = oracle.HostFrame(W, H, blue_noise), rt.DeviceFrame(W, H, blue_noise)
+    of, gf = oracle.HostFrame(W, H, blue_noise), rt.DeviceFrame(W, H, blue_noise, primary=primary)
     cfg = cfg or abi.SrTraceConfig.reference()
     prev = None
     for f in range(frames):
@@ -76,7 +83,9 @@ def run_both(rt, oracle, desc, W, H, frames, blue_noise, cfg=None, check_counter
         assert_bits_equal(of.raw_color, h["raw_color"], "raw_color f%d" % f)
         if check_counters:
             oc, gc = osc.counters(), gsc.counters()
-            assert (oc.closest_queries, oc.any_queries) == (gc.closest_queries, gc.any_queries)
+            assert (oc.closest_queries, oc.any_queries) == (ref_closest(gc), gc.any_queries)
+            # with the hand-off every pixel's camera ray is traversed once per frame (by the RIS pass), without it twice
+            assert gc.reused_primary_hits == (W * H if (cfg.enable_restir and cfg.virtual_bounces and gf.primary is not None) else 0)
     return osc, gsc, of, gf
 
 
@@ -338,6 +347,30 @@ def test_passes_match_committed_golden(rt, name, blue_noise):
 ])
 def test_passes_equal_oracle(rt, oracle, blue_noise, scene_fn, W, H, frames):
     run_both(rt, oracle, scene_fn(), W, H, frames, blue_noise)
+
+
+@pytest.mark.parametrize("scene_fn,W,H,frames", [
+    (scenes.cornell_glass_mirror, 200, 152, 3),
+    (small_atrium, 240, 136, 2),
+    (lambda: scenes.heightfield(n=300), 320, 180, 2),
+])
+def test_passes_without_the_primary_hit_hand_off(rt, oracle, blue_noise, scene_fn, W, H, frames):
+    """SrRtParams.primary_payload == NULL: the final pass traces its camera ray itself, as the reference does
+    (ray_gen_final.slang:80). Same bits as with the hand-off; the ray counters then hold every query of the reference."""
+    osc, gsc, of, gf = run_both(rt, oracle, scene_fn(), W, H, frames, blue_noise, primary=False)
+    c = gsc.counters()
+    assert c.reused_primary_hits == 0 and c.closest_queries >= 2 * W * H
+
+
+def test_primary_hit_hand_off_holds_the_camera_ray_payload(rt, oracle, blue_noise):
+    """What sr_trace_ris leaves in SrRtParams.primary_payload is the RayPayload of the camera ray — closest_hit / miss
+    applied to ray_gen_ris.slang:75 at virtual bounce 0 — for every pixel of the launch: compared with the payload the
+    oracle's RIS pass holds at that point, on a scene with glass, mirror and sky pixels, a textured one, over two frames."""
+    for desc, W, H in ((scenes.cornell_glass_mirror(), 96, 64), (small_atrium(), 120, 72)):
+        for frames in (1, 2):
+            osc, gsc, of, gf = run_both(rt, oracle, desc, W, H, frames, blue_noise)
+            got = gf.primary.cpu().numpy().view(np.uint32).reshape(-1).view(abi.RAY_PAYLOAD)
+            assert_bits_equal(of.primary, got, "primary payload")
 
 
 @pytest.mark.parametrize("W,H", [(5, 3), (8, 8), (130, 17), (1000, 9), (24, 300), (129, 129)])
@@ -999,7 +1032,7 @@ def test_4k_frame_1m_triangles(rt, oracle, blue_noise):
             sd.render_strip(gsc, gf2, m, 0, cfg, part, rank)
         assert_bits_equal(full, gf2.host()["raw_color"], "%d %s strips (+halo) compose to the 4K frame" % (world, axis))
         c = gsc.counters()      # halo pixels are traced but not counted: the strips' rays add up to the single launch's
-        assert (c.closest_queries, c.any_queries) == (single.closest_queries, single.any_queries)
+        assert (c.closest_queries, c.any_queries, c.reused_primary_hits) == (single.closest_queries, single.any_queries, single.reused_primary_hits)
         del gf2
 
 
@@ -1033,7 +1066,8 @@ def test_column_tiles_compose_and_count(rt, oracle, blue_noise):
     gsc.trace_ris(gf2, m, 0, cfg, tile=(0, 60, 20, 150)); osc.trace_ris(of, om, 0, cfg, tile=(0, 60, 20, 150))
     gsc.trace_final(gf2, m, 0, cfg, tile=(0, 60, 20, 150)); osc.trace_final(of, om, 0, cfg, tile=(0, 60, 20, 150))
     gc, oc = gsc.counters(), osc.counters()
-    assert (gc.closest_queries, gc.any_queries) == (oc.closest_queries, oc.any_queries) and 0 < gc.closest_queries < single_frame_closest(osc, of, om)
+    assert (ref_closest(gc), gc.any_queries) == (oc.closest_queries, oc.any_queries) and 0 < gc.closest_queries < single_frame_closest(osc, of, om)
+    assert gc.reused_primary_hits == 70 * 30
     with pytest.raises(Exception):
         gsc.trace_ris(gf2, m, 0, tile=(0, 0, W, 8))
 
