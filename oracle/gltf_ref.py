@@ -23,8 +23,9 @@ _COMP = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: n
 _NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
 
 
-def decode_png(data):
-    """8-bit PNG -> (h, w, channels) uint8 the way image-rs hands it to the gltf crate."""
+def decode_png(data, keep_16bit=False):
+    """8-bit PNG -> (h, w, channels) uint8 the way image-rs hands it to the gltf crate. keep_16bit: also accept 16-bit
+    samples (big-endian pairs) and return them as (h, w, channels) uint16 — the reference's blue-noise asset is one."""
     assert data[:8] == b"\x89PNG\r\n\x1a\n"
     pos, idat, plte, trns = 8, b"", None, None
     while pos < len(data):
@@ -41,7 +42,7 @@ def decode_png(data):
         elif typ == b"IEND":
             break
         pos += 12 + ln
-    assert interlace == 0 and depth in (1, 2, 4, 8)
+    assert interlace == 0 and (depth in (1, 2, 4, 8) or (depth == 16 and keep_16bit))
     samples = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
     stride = (w * samples * depth + 7) // 8
     bpp = max(samples * depth // 8, 1)
@@ -70,6 +71,10 @@ def decode_png(data):
                     p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
                 cur[x] = (line[x] + p) & 255
     img = img.astype(np.uint8)
+    if depth == 16:
+        assert ctype in (0, 2, 4, 6)
+        v = img.reshape(h, w * samples, 2).astype(np.uint16)
+        return np.ascontiguousarray(((v[..., 0] << 8) | v[..., 1]).reshape(h, w, samples))
     if depth < 8:
         bits = np.unpackbits(img, axis=1)[:, :w * samples * depth].reshape(h, w * samples, depth)
         vals = (bits * (1 << np.arange(depth - 1, -1, -1))).sum(axis=2)
@@ -122,14 +127,25 @@ class GltfRef:
     # accessor -> (count, ncomp) array; integer components are normalised like `into_f32()` when as_float
     def accessor(self, index, as_float=True):
         a = self.doc["accessors"][index]
-        assert "sparse" not in a
-        bv = self.doc["bufferViews"][a["bufferView"]]
         dt, nc = np.dtype(_COMP[a["componentType"]]), _NCOMP[a["type"]]
-        off = bv.get("byteOffset", 0) + a.get("byteOffset", 0)
-        stride = bv.get("byteStride", 0) or dt.itemsize * nc
-        buf = np.frombuffer(self.buffers[bv["buffer"]], dtype=np.uint8)
-        rows = np.lib.stride_tricks.as_strided(buf[off:], shape=(a["count"], dt.itemsize * nc), strides=(stride, 1))
-        arr = np.ascontiguousarray(rows).view(dt).reshape(a["count"], nc)
+
+        def rows_of(view, extra, count, itemsize, packed=False):
+            bv = self.doc["bufferViews"][view]
+            off = bv.get("byteOffset", 0) + extra
+            stride = itemsize if packed else (bv.get("byteStride", 0) or itemsize)
+            buf = np.frombuffer(self.buffers[bv["buffer"]], dtype=np.uint8)
+            return np.ascontiguousarray(np.lib.stride_tricks.as_strided(buf[off:], shape=(count, itemsize), strides=(stride, 1)))
+        if "bufferView" in a:
+            arr = rows_of(a["bufferView"], a.get("byteOffset", 0), a["count"], dt.itemsize * nc).view(dt).reshape(a["count"], nc)
+        else:
+            arr = np.zeros((a["count"], nc), dtype=dt)
+        if "sparse" in a:       # glTF 2.0 sparse accessor: `count` elements replaced at `indices` by tightly packed `values`
+            sp = a["sparse"]
+            idt = np.dtype(_COMP[sp["indices"]["componentType"]])
+            at = rows_of(sp["indices"]["bufferView"], sp["indices"].get("byteOffset", 0), sp["count"], idt.itemsize, True).view(idt).reshape(-1)
+            vals = rows_of(sp["values"]["bufferView"], sp["values"].get("byteOffset", 0), sp["count"], dt.itemsize * nc, True).view(dt).reshape(-1, nc)
+            arr = arr.copy()
+            arr[at.astype(np.int64)] = vals
         if not as_float:
             return arr.astype(np.uint32)
         if dt == np.float32:

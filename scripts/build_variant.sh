@@ -14,5 +14,5 @@ for s in kernels.hip post.hip bvh_gpu.hip api.cpp renderer.cpp gltf_load.cpp jpe
   if [ "$s" = "kernels.hip" ] || [ ! -f $obj ] || [ $src -nt $obj ]; then /opt/rocm/bin/hipcc $F "$@" $x -c $src -o $obj 2>&1 | grep -E "error" || true; fi
   objs="$objs $obj"
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libsunray_hip_$name.so $objs -pthread -lz
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libsunray_hip_$name.so $objs -pthread -lz -ldl
 echo $out/libsunray_hip_$name.so

@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-pthread", "-lz"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-pthread", "-lz", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -2,6 +2,7 @@
 // reference interface it replaces in the header; this file is the thin host layer between that ABI,
 // the host-side data preparation (host_prep.cpp, bvh_build.cpp) and the HIP kernels (kernels.hip).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 
@@ -41,6 +42,39 @@ namespace {
     } while (0)
 
 enum PassKind { kRis = 0, kFinal = 1, kClosest = 2, kAny = 3, kNumKinds = 4 };
+
+// Named profiler ranges around every pass, the counterpart of the debug-utils label the reference's render graph puts around
+// each pass (render_graph/graph.rs:1097-1118: a named scope in a capture, a no-op otherwise): rocTX push / pop around the
+// enqueue, visible in `rocprofv3 --marker-trace`. The rocTX library is looked up at first use (no link-time dependency);
+// without it, or with SR_PASS_LABELS=0 in the environment, the ranges are no-ops.
+struct PassLabel {
+    typedef int (*PushFn)(const char*);
+    typedef int (*PopFn)(void);
+    static void resolve(PushFn& push, PopFn& pop) {
+        static PushFn s_push = nullptr;
+        static PopFn s_pop = nullptr;
+        static bool tried = false;
+        if (!tried) {
+            tried = true;
+            const char* ev = getenv("SR_PASS_LABELS");
+            if (!(ev && atoi(ev) == 0)) {
+                void* h = nullptr;
+                for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"})   // rocprofv3 listens to the first
+                    if ((h = dlopen(name, RTLD_LAZY | RTLD_LOCAL))) break;
+                if (h) { s_push = (PushFn)dlsym(h, "roctxRangePushA"); s_pop = (PopFn)dlsym(h, "roctxRangePop"); }
+                if (!s_push || !s_pop) { s_push = nullptr; s_pop = nullptr; }
+            }
+        }
+        push = s_push; pop = s_pop;
+    }
+    PopFn pop = nullptr;
+    explicit PassLabel(const char* name) {
+        PushFn push;
+        resolve(push, pop);
+        if (push) push(name);
+    }
+    ~PassLabel() { if (pop) pop(); }
+};
 
 struct DeviceBuffer {
     void* p = nullptr;
@@ -888,6 +922,7 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
         a.tile_order = sched->have_order ? (const uint32_t*)sched->order.p : nullptr;
     }
     int e;
+    PassLabel label(name);
     {
         ScopedTiming tm(s, which == 0 ? kRis : kFinal, st);      // times the pass kernel only
         e = srk_launch_pass(a, which, s->instrumented, s->dev.shade_tex != nullptr, s->stack_entries, st);
@@ -961,6 +996,7 @@ static int check_post(const SrPostParams* p, const char* name, bool need_rt, boo
 int sr_post_temporal(const SrPostParams* p, void* stream) {
     int rc = check_post(p, "temporal_accumulation", true, false);
     if (rc != SR_OK) return rc;
+    PassLabel label("temporal_accumulation");
     int e = srk_launch_post_temporal(*p, (hipStream_t)stream);
     if (e != 0) return fail(SR_ERR_HIP, std::string("temporal_accumulation launch: ") + hipGetErrorString((hipError_t)e));
     return SR_OK;
@@ -968,6 +1004,7 @@ int sr_post_temporal(const SrPostParams* p, void* stream) {
 int sr_post_denoise(const SrPostParams* p, void* stream) {
     int rc = check_post(p, "denoise", false, true);
     if (rc != SR_OK) return rc;
+    PassLabel label("denoise");                                    // the reference's denoise_0 .. denoise_3 (lib.rs:1800-1870), one call here
     int e = srk_launch_post_denoise(*p, (hipStream_t)stream);
     if (e != 0) return fail(SR_ERR_HIP, std::string("denoise launch: ") + hipGetErrorString((hipError_t)e));
     return SR_OK;
@@ -976,6 +1013,7 @@ int sr_post_tonemap(const SrPostParams* p, void* stream) {
     int rc = check_post(p, "postprocess", false, false);
     if (rc != SR_OK) return rc;
     if (!p->output_rgba8) return fail(SR_ERR_INVALID_ARG, "postprocess: output image pointer is null");
+    PassLabel label("postprocess");
     int e = srk_launch_post_tonemap(*p, (hipStream_t)stream);
     if (e != 0) return fail(SR_ERR_HIP, std::string("postprocess launch: ") + hipGetErrorString((hipError_t)e));
     return SR_OK;

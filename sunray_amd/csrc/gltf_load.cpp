@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <string>
@@ -368,10 +369,21 @@ struct GltfLoader {
 
     // Accessor -> rows of `want_comps` floats (`into_f32`: normalized u8/u16/i8/i16 are divided by their max) or u32.
     struct View { const uint8_t* base = nullptr; size_t stride = 0, count = 0; int comp_type = 0, comps = 0; bool normalized = false; };
+    // Byte range [offset, offset + need) of a bufferView (+ extra offset); false when it leaves the buffer.
+    bool view_bytes(long view_index, size_t extra_offset, size_t need, const uint8_t** out) {
+        const Json* bv = element("bufferViews", view_index);
+        if (!bv) return fail("accessor without bufferView");
+        const long bi = bv->index("buffer");
+        if (bi < 0 || (size_t)bi >= buffers.size()) return fail("bufferView refers to a missing buffer");
+        const size_t off = bv->size_value("byteOffset") + extra_offset;
+        if (off > buffers[bi].size() || need > buffers[bi].size() - off) return fail("accessor exceeds its buffer");
+        *out = buffers[bi].data() + off;
+        return true;
+    }
+    std::deque<std::vector<uint8_t>> sparse_storage;      // materialised sparse accessors (Views point into these)
     bool accessor_view(long index, View& v) {
         const Json* a = element("accessors", index);
         if (!a) return fail("accessor index out of range");
-        if (a->has("sparse")) return fail("sparse accessors are not supported", SR_ERR_UNSUPPORTED);
         const Json* type = a->get("type");
         const std::string t = type && type->kind == Json::Str ? type->str : "";
         v.comps = t == "SCALAR" ? 1 : t == "VEC2" ? 2 : t == "VEC3" ? 3 : t == "VEC4" ? 4 : t == "MAT4" ? 16 : 0;
@@ -381,17 +393,49 @@ struct GltfLoader {
         v.count = a->size_value("count");
         const Json* nj = a->get("normalized");
         v.normalized = nj && nj->kind == Json::Bool && nj->b;
-        const Json* bv = element("bufferViews", a->index("bufferView"));
-        if (!bv) return fail("accessor without bufferView");
-        const long bi = bv->index("buffer");
-        if (bi < 0 || (size_t)bi >= buffers.size()) return fail("bufferView refers to a missing buffer");
-        const size_t off = bv->size_value("byteOffset") + a->size_value("byteOffset");
         const size_t elem = csz * v.comps;
-        v.stride = bv->size_value("byteStride");
-        if (v.stride == 0) v.stride = elem;
-        if (v.stride > 65536 || v.count > (1ull << 32)) return fail("accessor exceeds its buffer");
-        if (v.count && off + v.stride * (v.count - 1) + elem > buffers[bi].size()) return fail("accessor exceeds its buffer");
-        v.base = buffers[bi].data() + off;
+        const Json* sparse = a->get("sparse");
+        const bool has_view = a->index("bufferView") >= 0;
+        if (!has_view && !(sparse && sparse->kind == Json::Obj)) return fail("accessor without bufferView");
+        if (v.count > (1ull << 32)) return fail("accessor exceeds its buffer");
+        if (has_view) {
+            const Json* bv = element("bufferViews", a->index("bufferView"));
+            if (!bv) return fail("accessor without bufferView");
+            v.stride = bv->size_value("byteStride");
+            if (v.stride == 0) v.stride = elem;
+            if (v.stride > 65536) return fail("accessor exceeds its buffer");
+            if (!view_bytes(a->index("bufferView"), a->size_value("byteOffset"), v.count ? v.stride * (v.count - 1) + elem : 0, &v.base)) return false;
+        }
+        if (!sparse) return true;
+        // Sparse accessor (glTF 2.0 §3.6.2.3, what the gltf crate's accessor::Iter resolves transparently for the readers of
+        // gltf/mod.rs:57-67): the bufferView's elements — zeros without one — with `count` of them replaced by tightly packed
+        // `values` at the strictly increasing positions `indices`. Materialised once, tightly packed.
+        if (sparse->kind != Json::Obj) return fail("sparse accessor: malformed sparse object");
+        const size_t n_sub = sparse->size_value("count");
+        const Json* ji = sparse->get("indices");
+        const Json* jv = sparse->get("values");
+        if (!ji || ji->kind != Json::Obj || !jv || jv->kind != Json::Obj || n_sub == 0 || n_sub > v.count) return fail("sparse accessor: needs count (1..accessor count), indices and values");
+        const int ict = (int)ji->number("componentType", 0);
+        const size_t isz = ict == 5121 ? 1 : ict == 5123 ? 2 : ict == 5125 ? 4 : 0;
+        if (!isz) return fail("sparse accessor: indices must be u8 / u16 / u32");
+        const uint8_t *ip = nullptr, *vp = nullptr;
+        if (!view_bytes(ji->index("bufferView"), ji->size_value("byteOffset"), n_sub * isz, &ip)) return false;
+        if (!view_bytes(jv->index("bufferView"), jv->size_value("byteOffset"), n_sub * elem, &vp)) return false;
+        sparse_storage.emplace_back(v.count * elem, (uint8_t)0);
+        std::vector<uint8_t>& dst = sparse_storage.back();
+        if (has_view) for (size_t i = 0; i < v.count; i++) memcpy(dst.data() + i * elem, v.base + i * v.stride, elem);
+        long long last = -1;
+        for (size_t k = 0; k < n_sub; k++) {
+            uint32_t at = 0;
+            if (isz == 1) at = ip[k];
+            else if (isz == 2) { uint16_t u; memcpy(&u, ip + 2 * k, 2); at = u; }
+            else memcpy(&at, ip + 4 * k, 4);
+            if ((long long)at <= last || at >= v.count) return fail("sparse accessor: indices must be strictly increasing and inside the accessor");
+            last = at;
+            memcpy(dst.data() + (size_t)at * elem, vp + k * elem, elem);
+        }
+        v.base = dst.data();
+        v.stride = elem;
         return true;
     }
     static float component_f32(const uint8_t* p, int ct, bool normalized) {

@@ -621,7 +621,10 @@ def test_renderer_render_to_host_memory_equals_oracle(rt, oracle):
 
 def test_renderer_with_a_host_supplied_noise_texture(rt, oracle):
     """lib.rs:281-309: the reference embeds a 16-bit greyscale PNG and uploads its to_rgba8() form. A host that owns that asset
-    decodes it (sr_decode_image_rgba8) and hands it to the renderer; here a synthetic 16-bit PNG of another extent stands in."""
+    decodes it (sr_decode_image_rgba8) and hands it to the renderer; here a synthetic 16-bit PNG of another extent stands in.
+    The texture feeds the first BRDF bounce (ray_gen_final.slang:44-50,393-396). With ReSTIR on, every first rough hit ends the
+    walk (:327), so that branch is reached after specular chains only; with enable_restir = 0 every rough first hit bounces
+    with the texture's numbers — there two different textures MUST give different images, and each must equal the oracle's."""
     import struct
     import zlib
     rng = np.random.default_rng(77)
@@ -633,18 +636,97 @@ def test_renderer_with_a_host_supplied_noise_texture(rt, oracle):
            chunk(b"IDAT", zlib.compress(b"".join(b"\x00" + v[y].astype(">u2").tobytes() for y in range(48)))) + chunk(b"IEND", b""))
     noise = rt.decode_image_rgba8(png)
     assert noise.shape == (48, 64, 4) and (noise[..., 0] == ((v.astype(np.uint32) + 128) // 257)).all() and (noise[..., 3] == 255).all()
-    desc = scenes.cornell_glass_mirror()          # specular first bounces: the passes sample the texture (ray_gen_final.slang:44-50,397-399)
+    desc = scenes.cornell_glass_mirror()
     W, H = 72, 56
+    cam = (desc.camera_pos, desc.camera_target, desc.fov_y)
+    images = []
+    for restir in (1, 0):
+        cfg = abi.SrTraceConfig.reference()
+        cfg.enable_restir = restir
+        for tex in (noise, rt.default_noise_texture()):
+            r = rt.Renderer((W, H))
+            r.set_config(cfg)
+            r.set_blue_noise(tex)
+            for m in desc.meshes:
+                r.load_mesh(m.key, m.vertices, m.indices, m.material)
+            img = r.render_to_host_memory(cam, desc.instances)
+            osc = oracle.OracleScene().load(desc)
+            of, prev = oracle.HostFrame(W, H, tex), None
+            for f in range(16):
+                om = oracle.camera_matrices(cam[0], cam[1], cam[2], W, H, prev)
+                prev = list(om.view_proj)
+                if restir:
+                    osc.trace_ris(of, om, f, cfg)
+                osc.trace_final(of, om, f, cfg)
+                oracle.post_chain(of, f)
+            assert_bits_equal(of.output, img.view(np.uint32).reshape(-1), "render_to_host_memory with a host-supplied noise texture (restir %d)" % restir)
+            images.append(img)
+            if restir == 0:
+                with pytest.raises(rt.SunrayError):
+                    r.set_blue_noise(np.zeros((0, 4, 4), dtype=np.uint8))
+            r.close()
+    assert (images[2] != images[3]).any(), "the noise texture does not reach the image"
+
+
+REF_ASSET_DIR = os.path.join(GOLDEN, "ref_assets")     # the reference's example rooms and its blue-noise PNG (data files)
+PNG_EXAMPLE_CAMERA = ((13.0, 30.0, 25.0), (0.0, 13.0, 0.0), 45.0)      # examples/png/main.rs:52-55
+
+
+def _render_ref_asset(rt, oracle, name, W, H, frames, noise):
+    """Renderer::load_gltf + `frames` x (render, wait_frame) of one of the reference's example rooms against the oracle's
+    restatement of the same loop; returns (gpu RGBA8 image, seconds per frame on the GPU for a second, pipelined run)."""
+    import time
+    import torch
+    path = os.path.join(REF_ASSET_DIR, name)
     r = rt.Renderer((W, H))
     r.set_blue_noise(noise)
-    for m in desc.meshes:
-        r.load_mesh(m.key, m.vertices, m.indices, m.material)
-    img = r.render_to_host_memory((desc.camera_pos, desc.camera_target, desc.fov_y), desc.instances)
-    of, _ = _oracle_render_to_host_memory(oracle, desc, W, H, [desc.instances] * 16, noise)
-    assert_bits_equal(of.output, img.view(np.uint32).reshape(-1), "render_to_host_memory with a host-supplied noise texture")
-    with pytest.raises(rt.SunrayError):
-        r.set_blue_noise(np.zeros((0, 4, 4), dtype=np.uint8))
+    group, inst = r.load_gltf(path)
+    osc, grouped, keys, n_img = _oracle_scene_from_gltf(oracle, path, 0, 0, {})
+    assert [k for k, _ in inst] == keys and n_img == 0
+    if frames == 16:
+        img = r.render_to_host_memory(PNG_EXAMPLE_CAMERA, inst)
+    else:
+        for _ in range(frames):
+            fr = r.render(PNG_EXAMPLE_CAMERA, inst)
+        r.wait_frame(fr)
+        import ctypes as C
+        from sunray_amd._lib import lib
+        outp = C.c_void_p()
+        assert lib().sr_renderer_get(r._h, None, C.byref(outp), None, None) == 0
+        img = np.zeros((H, W, 4), dtype=np.uint8)
+        assert C.CDLL("libamdhip64.so").hipMemcpy(img.ctypes.data_as(C.c_void_p), outp, C.c_size_t(img.nbytes), C.c_int(2)) == 0
+    osc.set_instances(grouped)
+    of, _ = _oracle_frames(oracle, osc, PNG_EXAMPLE_CAMERA, W, H, frames, noise)
+    assert_bits_equal(of.output, img.view(np.uint32).reshape(-1), "%s %dx%d, %d frames" % (name, W, H, frames))
+    # frame time of the same workload with two frames in flight (not part of the parity claim)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(32):
+        fr = r.render(PNG_EXAMPLE_CAMERA, inst)
+    r.wait_frame(fr)
+    dt = (time.perf_counter() - t0) / 32
     r.close()
+    return img, dt
+
+
+def test_reference_png_example_workload(rt, oracle):
+    """The reference's own offline workload (examples/png/main.rs:43-61, src/lib.rs:1908-1934): ReflectionRoom.glb (1 986
+    triangles, one emissive material of strength 61.6, one transmissive), 1600x1200, the crate's blue-noise texture
+    (lib.rs:281-284: noise.png, 128x128 16-bit grey, through to_rgba8), camera (13, 30, 25) -> (0, 13, 0), fov 45,
+    render_to_host_memory = 16 frames. Every byte of the RGBA8 image against the oracle's restatement of that loop."""
+    noise = rt.decode_image_rgba8(open(os.path.join(REF_ASSET_DIR, "noise.png"), "rb").read())
+    assert noise.shape == (128, 128, 4)
+    img, dt = _render_ref_asset(rt, oracle, "ReflectionRoom.glb", 1600, 1200, 16, noise)
+    assert (img[..., 3] == 255).all() and len(np.unique(img.reshape(-1, 4), axis=0)) > 2000
+    print("ReflectionRoom.glb 1600x1200: %.3f ms per frame (whole frame incl. post chain, two in flight)" % (dt * 1e3))
+
+
+@pytest.mark.parametrize("name", ["ReflectionRoom3.glb", "Room.glb", "Room2.glb", "Room3.glb"])
+def test_reference_example_rooms(rt, oracle, name):
+    """The other four example rooms of the reference at 400x300, two frames (temporal reuse active), same camera and noise."""
+    noise = rt.decode_image_rgba8(open(os.path.join(REF_ASSET_DIR, "noise.png"), "rb").read())
+    img, dt = _render_ref_asset(rt, oracle, name, 400, 300, 2, noise)
+    assert img[..., :3].any()
 
 
 def test_renderer_resize_and_instance_change(rt, oracle):
