@@ -16,8 +16,12 @@ bn = scenes.white_noise_rgba8()
 sc = rt.Scene(0).load(desc)
 fr = rt.DeviceFrame(W, H, bn)
 prev = None
-RIS = ["primary", "later virtual bounces", "DI visibility", "GI bounce (closest)", "NEE at GI hit", "-", "-", "-", "-", "-", "-", "TOTAL wave time"]
-FIN = ["primary", "later closest", "DI shadow", "GI neighbour 0", "GI neighbour 1", "GI neighbour 2", "GI final visibility", "NEE", "-", "-", "-", "TOTAL wave time"]
+RIS = ["setup + shading between virtual bounces", "TRAVERSAL primary", "TRAVERSAL later virtual bounces", "G-buffer / motion after the walk", "16 RIS candidates",
+       "reservoir W + temporal DI reuse", "DI visibility ray setup", "TRAVERSAL DI visibility", "store DI, GI sample direction", "TRAVERSAL GI bounce (closest)",
+       "NEE sample at the GI hit", "TRAVERSAL NEE at GI hit", "GI reservoir initial weights", "GI temporal reuse + stores"]
+FIN = ["setup (rng, noise, camera ray)", "TRAVERSAL closest", "payload load + material decode", "DI: centre reservoir", "DI: 5 spatial neighbours", "DI: winner, shadow ray setup",
+       "TRAVERSAL DI shadow", "GI: 3 neighbour candidates + merges", "TRAVERSAL GI neighbours", "GI: last merge", "GI: final weight, ray setup", "TRAVERSAL GI final visibility",
+       "NEE setup (later bounces)", "TRAVERSAL NEE", "contributions, BRDF bounce, store"]
 
 
 def misc():
@@ -26,23 +30,31 @@ def misc():
     return np.array(list(out), dtype=np.float64)
 
 
+def show(name, labels, t):
+    tot = t.sum()
+    print("  %s: share of summed wave time" % name)
+    for i, l in enumerate(labels):
+        if t[i] > 0:
+            print("    %-44s %5.1f %%" % (l, 100 * t[i] / tot))
+    trav = sum(t[i] for i, l in enumerate(labels) if l.startswith("TRAVERSAL"))
+    print("    %-44s %5.1f %%" % ("= traversal in all", 100 * trav / tot))
+
+
 for f in range(12):
     m = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, W, H, prev)
     prev = list(m.view_proj)
-    sc.reset_counters()
     torch.cuda.synchronize()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    e[0].record(); sc.trace_ris(fr, m, f); e[1].record(); sc.trace_final(fr, m, f); e[2].record()
+    sc.reset_counters()
+    e[0].record(); sc.trace_ris(fr, m, f); e[1].record()
     torch.cuda.synchronize()
-    if f < 9:
+    v1 = misc()
+    sc.reset_counters()
+    e[1].record(); sc.trace_final(fr, m, f); e[2].record()
+    torch.cuda.synchronize()
+    v2 = misc()
+    if f < 10:
         continue
-    v = misc()
-    print("frame %d: ris %.3f ms final %.3f ms; closest %d any %d reused %d" % (f, e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), v[0], v[1], v[4]))
-    for name, base, labels in (("ris_kernel", 8, RIS), ("final_kernel", 20, FIN)):
-        t = v[base:base + 12]
-        tot = t[11]
-        print("  %s: share of summed wave time per call site" % name)
-        for i in range(11):
-            if t[i] > 0:
-                print("    %-24s %5.1f %%" % (labels[i], 100 * t[i] / tot))
-        print("    %-24s %5.1f %%" % ("outside traversal", 100 * (tot - t[:11].sum()) / tot))
+    print("frame %d: ris %.3f ms final %.3f ms" % (f, e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])))
+    show("ris_kernel", RIS, v1[8:8 + len(RIS)])
+    show("final_kernel", FIN, v2[8:8 + len(FIN)])

@@ -3,6 +3,9 @@
 hipcc cross-compiles gfx950 code objects without a GPU. Flags that matter for parity:
   -ffp-contract=off                         no implicit FMA fusion, host and device
   -fhip-fp32-correctly-rounded-divide-sqrt  IEEE divide/sqrt on the device
+Code generation only (same IEEE operation per element, same bits):
+  -fno-slp-vectorize                        no v_pk_*_f32: a packed fp32 instruction takes two issue slots on gfx950 and the
+                                            register pairs it needs cost the final pass 10 spilled VGPRs and ~100 v_mov
 """
 import os
 import subprocess
@@ -14,7 +17,7 @@ LIB = os.path.join(HERE, "libsunray_hip.so")
 SOURCES = ["kernels.hip", "post.hip", "bvh_gpu.hip", "api.cpp", "renderer.cpp", "gltf_load.cpp", "jpeg_decode.cpp", "host_prep.cpp", "bvh_build.cpp"]
 HEADERS = ["rt_device.h", "traverse.h", "kernels.h", "host.h", "bvh_gpu.h", os.path.join("..", "..", "include", "sunray_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-pthread"]
 
 
