@@ -605,6 +605,58 @@ int sr_scene_read_tile_row_costs(SrScene* scene, int which, uint32_t width, uint
 int sr_scene_read_tile_costs(SrScene* scene, int which, uint32_t width, uint32_t y0, uint32_t rows, uint32_t* out,
                              uint32_t cap, uint32_t* n_tiles);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Tile-parallel rendering across the GPUs of a node                               */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference renders on one device (src/lib.rs:1166). A multi-GPU host creates one scene / renderer context per GPU
+ * (scene replicated), cuts the frame into `world` contiguous strips and has every context trace its strip into full-size
+ * buffers; pixels are keyed by global coordinates (tile_* of SrRtParams), so the strips of N contexts are the single-GPU
+ * frame bit for bit. ReSTIR's spatial reuse reads a 30-pixel neighbourhood (ray_gen_final.slang:160-188,228-247): the RIS
+ * pass of a strip also covers a 30-pixel halo on either side (recomputed, rays counted for the strip only). Temporal reuse
+ * under camera motion needs the reservoir bands sr_history_exchange_plan lists, from the ranks that own them. The only
+ * data-path collective is the gather of the radiance strips, which stays with the caller (RCCL: ncclAllGather over the
+ * per-rank raw_color strips). Everything here is deterministic host arithmetic: every rank derives the
+ * same partition and plans from the same inputs. */
+#define SR_AXIS_COLS 0u      /* column strips (default: image cost varies mostly with the row, columns hand every GPU the same mix) */
+#define SR_AXIS_ROWS 1u
+#define SR_SPATIAL_HALO 30u  /* SPATIAL_RADIUS (ray_gen_final.slang:161) >= GI_SPATIAL_RADIUS (:229) */
+typedef struct SrPartition SrPartition;
+/* `bounds`: world + 1 increasing cut positions along the axis from 0 to its length (e.g. from sr_balanced_bounds), or NULL for
+ * equal strips. A partition must stay the same for a whole frame sequence: a rank owns the temporal history of its strip + halo. */
+int sr_partition_create(uint32_t width, uint32_t height, uint32_t world, uint32_t axis, const uint32_t* bounds, SrPartition** out);
+int sr_partition_destroy(SrPartition* partition);
+int sr_partition_get(const SrPartition* partition, uint32_t* width, uint32_t* height, uint32_t* world, uint32_t* axis, const uint32_t** bounds);
+/* (start, size) along the axis of rank's strip grown by `grow` positions on both sides, clipped to the image. */
+int sr_partition_span(const SrPartition* partition, uint32_t rank, uint32_t grow, uint32_t* start, uint32_t* size);
+/* Cuts a per-position cost profile into `world` strips of (nearly) equal summed cost, each at least min_size positions and at
+ * most max_share * length / world (the gather pads strips to the largest): bounds_out receives world + 1 cuts. */
+int sr_balanced_bounds(const double* cost, uint32_t length, uint32_t world, uint32_t min_size, double max_share, uint32_t* bounds_out);
+/* Per-column / per-row cost profile (length entries) from per-tile costs (sr_scene_read_tile_costs, tiles_y x tiles_x, 8x8 pixels). */
+int sr_axis_cost_from_tiles(const double* tile_costs, uint32_t tiles_x, uint32_t tiles_y, uint32_t axis, uint32_t length, double* out);
+/* One point-to-point transfer of the temporal-history exchange: positions [start, start + size) along the axis, full extent
+ * across it, of BOTH current reservoir buffers (reservoirs[frame_count & 1], reservoirs_gi[frame_count & 1]), src -> dst. */
+typedef struct SrStripTransfer {
+    uint32_t src, dst, start, size;
+} SrStripTransfer;
+/* The transfers needed after every RIS pass when temporal reprojection can move a pixel by up to motion_halo positions along
+ * the axis between frames (0 = static camera: none). Writes at most cap entries, returns the total through *count. */
+int sr_history_exchange_plan(const SrPartition* partition, uint32_t motion_halo, SrStripTransfer* out, uint32_t cap, uint32_t* count);
+/* Launch rectangles of rank's share of a frame: what sr_strip_trace_ris / sr_strip_trace_final put into SrRtParams.tile_* and
+ * SrTraceConfig.count_* (count_window == 0: no counting window, every traced pixel counts). */
+typedef struct SrStripRects {
+    uint32_t ris_y0, ris_h, ris_x0, ris_w;          /* raytracing_ris: strip + spatial halo (world > 1) */
+    uint32_t final_y0, final_h, final_x0, final_w;  /* raytracing_final: the strip */
+    uint32_t count_y0, count_rows, count_x0, count_cols;
+    uint32_t count_window;
+    uint32_t empty;                                 /* the rank's strip has no pixels: nothing to launch */
+} SrStripRects;
+int sr_strip_rects(const SrPartition* partition, uint32_t rank, SrStripRects* out);
+/* sr_trace_ris / sr_trace_final of rank's share: `params` describes the whole frame on this rank's device (full-size buffers);
+ * its tile_* and config.count_* fields are replaced. Same stream rules as sr_trace_*; between the two calls the host performs
+ * the transfers of sr_history_exchange_plan (if any) on the same stream. */
+int sr_strip_trace_ris(const SrRtParams* params, const SrPartition* partition, uint32_t rank, void* stream);
+int sr_strip_trace_final(const SrRtParams* params, const SrPartition* partition, uint32_t rank, void* stream);
+
 /* Ray counters since the last reset (device-side atomics, read back synchronously). */
 int sr_scene_reset_counters(SrScene* scene, void* stream);
 int sr_scene_read_counters(SrScene* scene, void* stream, SrRayCounters* out);
@@ -637,6 +689,7 @@ static_assert(sizeof(SrRayPayload) == 32, "T8");
 static_assert(sizeof(SrRay) == 32 && sizeof(SrHit) == 16, "ray/hit");
 static_assert(sizeof(SrTraceConfig) == 40 && sizeof(SrRtParams) == 184, "T9");
 static_assert(sizeof(SrPostParams) == 104, "post params");
+static_assert(sizeof(SrStripTransfer) == 16 && sizeof(SrStripRects) == 56, "strip plans");
 #endif
 
 #endif /* SUNRAY_HIP_H */

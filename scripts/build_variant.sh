@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 out=sunray_amd/_variants; mkdir -p $out/obj_$name
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-slp-vectorize -pthread"
 objs=""
-for s in kernels.hip post.hip bvh_gpu.hip api.cpp renderer.cpp gltf_load.cpp jpeg_decode.cpp host_prep.cpp bvh_build.cpp; do
+for s in kernels.hip post.hip bvh_gpu.hip api.cpp renderer.cpp multi_gpu.cpp gltf_load.cpp jpeg_decode.cpp host_prep.cpp bvh_build.cpp; do
   x=""; case $s in *.cpp) x="-x hip";; esac
   src=sunray_amd/csrc/$s; obj=$out/obj_$name/$s.o
   if [ "$s" = "kernels.hip" ] || [ ! -f $obj ] || [ $src -nt $obj ]; then /opt/rocm/bin/hipcc $F "$@" $x -c $src -o $obj 2>&1 | grep -E "error" || true; fi

@@ -144,3 +144,17 @@ class SrAsState(C.Structure):
 
 BUILD_RAPIDLY_CHANGING, BUILD_SOMETIMES_CHANGES, BUILD_STATIC = 0, 1, 2
 OP_NONE, OP_SLOW_BUILD, OP_FAST_BUILD, OP_UPDATE = 0, 1, 2, 3
+
+
+class SrStripTransfer(C.Structure):  # one point-to-point transfer of the temporal-history exchange
+    _fields_ = [("src", C.c_uint32), ("dst", C.c_uint32), ("start", C.c_uint32), ("size", C.c_uint32)]
+
+
+class SrStripRects(C.Structure):  # launch rectangles + counting window of one rank's share of a frame
+    _fields_ = [("ris_y0", C.c_uint32), ("ris_h", C.c_uint32), ("ris_x0", C.c_uint32), ("ris_w", C.c_uint32),
+                ("final_y0", C.c_uint32), ("final_h", C.c_uint32), ("final_x0", C.c_uint32), ("final_w", C.c_uint32),
+                ("count_y0", C.c_uint32), ("count_rows", C.c_uint32), ("count_x0", C.c_uint32), ("count_cols", C.c_uint32),
+                ("count_window", C.c_uint32), ("empty", C.c_uint32)]
+
+
+AXIS_COLS, AXIS_ROWS, SPATIAL_HALO = 0, 1, 30

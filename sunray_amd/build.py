@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsunray_hip.so")
-SOURCES = ["kernels.hip", "post.hip", "bvh_gpu.hip", "api.cpp", "renderer.cpp", "gltf_load.cpp", "jpeg_decode.cpp", "host_prep.cpp", "bvh_build.cpp"]
+SOURCES = ["kernels.hip", "post.hip", "bvh_gpu.hip", "api.cpp", "renderer.cpp", "multi_gpu.cpp", "gltf_load.cpp", "jpeg_decode.cpp", "host_prep.cpp", "bvh_build.cpp"]
 HEADERS = ["rt_device.h", "traverse.h", "kernels.h", "host.h", "bvh_gpu.h", os.path.join("..", "..", "include", "sunray_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",

@@ -18,33 +18,62 @@ ReSTIR makes pixels depend on neighbours:
     out, in pixels this rank never traced: `exchange_history` fetches those reservoir bands from the ranks that own them
     (point-to-point over RCCL / gloo) after every RIS pass, so the history a rank reads is always the single-GPU one and
     N-GPU output stays bit-identical to 1-GPU for a moving camera as well (tests/test_distributed_gloo.py).
+The strip geometry, the cost-balanced cut, the history-exchange plan and the two strip launches live in the library behind the
+C ABI (csrc/multi_gpu.cpp: sr_partition_*, sr_balanced_bounds, sr_axis_cost_from_tiles, sr_history_exchange_plan, sr_strip_*):
+a Rust host calls the same entry points. This module binds them and adds what needs torch: the point-to-point
+history exchange, the frame pipeline (streams + events) and the double-buffered asynchronous gather.
 """
 import copy
 
 SPATIAL_HALO = 30  # SPATIAL_RADIUS (ray_gen_final.slang:161) >= GI_SPATIAL_RADIUS (:229)
 
 
+def _u32(n):
+    import ctypes as C
+    return (C.c_uint32 * n)()
+
+
 class Partition:
-    """`world` contiguous strips of a width x height image along one axis. `bounds` (world + 1 increasing cut positions,
-    e.g. from balanced_bounds) replaces the equal split; it must stay the same for a whole frame sequence: a rank owns
-    the temporal history of exactly its strip + halo."""
+    """`world` contiguous strips of a width x height image along one axis — a handle on the library's SrPartition
+    (csrc/multi_gpu.cpp), which owns the geometry. `bounds` (world + 1 increasing cut positions, e.g. from balanced_bounds)
+    replaces the equal split; it must stay the same for a whole frame sequence: a rank owns the temporal history of exactly
+    its strip + halo."""
 
     def __init__(self, width, height, world, axis="cols", bounds=None):
+        import ctypes as C
+        from ._lib import check, lib
         if axis not in ("cols", "rows"):
             raise ValueError("axis must be 'cols' or 'rows'")
-        self.width, self.height, self.world, self.axis = width, height, world, axis
-        self.length = width if axis == "cols" else height
-        if bounds is None:
-            per = (self.length + world - 1) // world
-            bounds = [min(r * per, self.length) for r in range(world)] + [self.length]
-        bounds = [int(v) for v in bounds]
-        if len(bounds) != world + 1 or bounds[0] != 0 or bounds[-1] != self.length or any(b > a for b, a in zip(bounds, bounds[1:])):
-            raise ValueError("bounds must be %d increasing cuts from 0 to %d" % (world + 1, self.length))
-        self.bounds = bounds
+        self.width, self.height, self.world, self.axis = int(width), int(height), int(world), axis
+        self.length = self.width if axis == "cols" else self.height
+        b = None
+        if bounds is not None:
+            bounds = [int(v) for v in bounds]
+            if len(bounds) != world + 1 or any(v < 0 for v in bounds):
+                raise ValueError("bounds must be %d increasing cuts from 0 to %d" % (world + 1, self.length))
+            b = (C.c_uint32 * len(bounds))(*bounds)
+        self._h = C.c_void_p()
+        try:
+            check(lib().sr_partition_create(C.c_uint32(self.width), C.c_uint32(self.height), C.c_uint32(self.world),
+                                            C.c_uint32(0 if axis == "cols" else 1), b, C.byref(self._h)))
+        except Exception as e:
+            raise ValueError(str(e))
+        bp = C.POINTER(C.c_uint32)()
+        check(lib().sr_partition_get(self._h, None, None, None, None, C.byref(bp)))
+        self.bounds = [int(bp[i]) for i in range(self.world + 1)]
+
+    def __del__(self):
+        try:
+            from ._lib import lib
+            if getattr(self, "_h", None):
+                lib().sr_partition_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     def span(self, rank):
         """(start, size) of rank's strip along the axis."""
-        return self.bounds[rank], self.bounds[rank + 1] - self.bounds[rank]
+        return self.grown(rank, 0)
 
     def sizes(self):
         return [self.bounds[r + 1] - self.bounds[r] for r in range(self.world)]
@@ -55,9 +84,20 @@ class Partition:
 
     def grown(self, rank, grow):
         """(start, size) of rank's strip grown by `grow` on both sides, clipped to the image."""
-        a0, n = self.span(rank)
-        lo, hi = max(0, a0 - grow), min(self.length, a0 + n + grow)
-        return lo, hi - lo
+        import ctypes as C
+        from ._lib import check, lib
+        a, n = C.c_uint32(), C.c_uint32()
+        check(lib().sr_partition_span(self._h, C.c_uint32(rank), C.c_uint32(grow), C.byref(a), C.byref(n)))
+        return a.value, n.value
+
+    def rects(self, rank):
+        """SrStripRects of rank: the launch rectangles and counting window of its share of a frame."""
+        import ctypes as C
+        from . import abi
+        from ._lib import check, lib
+        r = abi.SrStripRects()
+        check(lib().sr_strip_rects(self._h, C.c_uint32(rank), C.byref(r)))
+        return r
 
     def view(self, flat, channels=None):
         """[H, W(, C)] view of a per-pixel buffer (torch tensor or numpy array of H*W rows)."""
@@ -69,87 +109,84 @@ class Partition:
 
 
 def balanced_bounds(cost, world, min_size=8, max_share=2.5):
-    """Cuts positions 0 .. len(cost) into `world` contiguous strips of (nearly) equal summed cost: returns world + 1
-    increasing cut positions. Strips are cut one after the other, each taking 1/n of the cost that is left for the n ranks
-    that are left, with at least `min_size` positions and at most max_share * length / world (the gather pads every strip
-    to the largest one, so a very large cheap strip would inflate the collective). Deterministic: every rank that feeds
-    the same profile gets the same cut."""
+    """Cuts positions 0 .. len(cost) into `world` contiguous strips of (nearly) equal summed cost (sr_balanced_bounds): returns
+    world + 1 increasing cut positions; every strip has at least `min_size` positions and at most max_share * length / world
+    (the gather pads every strip to the largest one). Deterministic: every rank that feeds the same profile gets the same cut."""
+    import ctypes as C
     import numpy as np
-    cost = np.maximum(np.asarray(cost, dtype=np.float64), 0.0) + 1e-12
-    length = len(cost)
-    min_size = max(1, min(min_size, length // max(world, 1)))
-    max_size = max(int(np.ceil(max_share * length / max(world, 1))), min_size)
-    cum = np.concatenate([[0.0], np.cumsum(cost)])
-    bounds = [0]
-    for k in range(world - 1):
-        y, n = bounds[-1], world - k
-        target = cum[y] + (cum[-1] - cum[y]) / n
-        cut = int(np.searchsorted(cum, target, side="left"))
-        cut = min(max(cut, y + min_size), y + max_size)          # this strip: [min_size, max_size]
-        cut = max(cut, length - (n - 1) * max_size)              # the ranks that are left can still cover the rest ...
-        cut = min(cut, length - (n - 1) * min_size)              # ... and each gets its minimum
-        bounds.append(max(cut, y))
-    bounds.append(length)
-    return [int(v) for v in bounds]
+    from ._lib import check, lib
+    c = np.ascontiguousarray(cost, dtype=np.float64)
+    out = _u32(world + 1)
+    check(lib().sr_balanced_bounds(c.ctypes.data_as(C.c_void_p), C.c_uint32(len(c)), C.c_uint32(world), C.c_uint32(min_size), C.c_double(max_share), out))
+    return [int(v) for v in out]
 
 
 def axis_cost_from_tiles(tile_costs, tiles_x, axis, length, tile=8):
     """Per-pixel-column (or per-pixel-row) cost from the per-tile cycle counts the library records for its own tile
-    schedule (sr_scene_read_tile_costs, row-major ty * tiles_x + tx): what balanced_bounds cuts."""
+    schedule (sr_scene_read_tile_costs, row-major ty * tiles_x + tx): what balanced_bounds cuts (sr_axis_cost_from_tiles)."""
+    import ctypes as C
     import numpy as np
-    t = np.asarray(tile_costs, dtype=np.float64).reshape(-1, tiles_x)
-    per_tile = t.sum(axis=0) if axis == "cols" else t.sum(axis=1)
-    return np.repeat(per_tile / float(tile), tile)[:length]
+    from ._lib import check, lib
+    assert tile == 8
+    t = np.ascontiguousarray(tile_costs, dtype=np.float64).reshape(-1, tiles_x)
+    out = np.zeros(length, dtype=np.float64)
+    check(lib().sr_axis_cost_from_tiles(t.ctypes.data_as(C.c_void_p), C.c_uint32(tiles_x), C.c_uint32(t.shape[0]), C.c_uint32(0 if axis == "cols" else 1),
+                                        C.c_uint32(length), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def _is_device_scene(scene):
+    from . import runtime
+    return isinstance(scene, runtime.Scene)
 
 
 def trace_ris_strip(scene, frame, matrices, frame_count, cfg, part, rank):
     """The RIS pass of this rank's strip. With world > 1 it is ONE launch over the strip and its spatial halo: a rank's
     share of a frame is small, so every extra launch adds a tail in which the GPU drains; only the strip's own pixels
-    count their rays."""
-    a0, n = part.span(rank)
-    if n <= 0 or not cfg.enable_restir:
+    count their rays. A device scene goes through sr_strip_trace_ris; the CPU tests' oracle scene gets the same rectangles
+    (sr_strip_rects) through its own trace_ris."""
+    import ctypes as C
+    from ._lib import check, lib
+    if _is_device_scene(scene):
+        p = scene.params(frame, matrices, frame_count, cfg)
+        check(lib().sr_strip_trace_ris(C.byref(p), part._h, C.c_uint32(rank), scene._stream()))
         return
-    if part.world > 1:
-        g0, gn = part.grown(rank, SPATIAL_HALO)
-        rcfg = copy.copy(cfg)
-        if part.axis == "cols":
-            rcfg.count_x0, rcfg.count_cols = a0, n
-        else:
-            rcfg.count_y0, rcfg.count_rows = a0, n
-        scene.trace_ris(frame, matrices, frame_count, rcfg, tile=part.tile(g0, gn))
-    else:
-        scene.trace_ris(frame, matrices, frame_count, cfg, tile=part.tile(a0, n))
+    r = part.rects(rank)
+    if r.empty or not cfg.enable_restir:
+        return
+    rcfg = copy.copy(cfg)
+    if r.count_window:
+        rcfg.count_y0, rcfg.count_rows, rcfg.count_x0, rcfg.count_cols = r.count_y0, r.count_rows, r.count_x0, r.count_cols
+    scene.trace_ris(frame, matrices, frame_count, rcfg, tile=(r.ris_y0, r.ris_h, r.ris_x0, r.ris_w))
 
 
 def trace_final_strip(scene, frame, matrices, frame_count, cfg, part, rank):
-    a0, n = part.span(rank)
-    if n > 0:
-        scene.trace_final(frame, matrices, frame_count, cfg, tile=part.tile(a0, n))
+    import ctypes as C
+    from ._lib import check, lib
+    if _is_device_scene(scene):
+        p = scene.params(frame, matrices, frame_count, cfg)
+        check(lib().sr_strip_trace_final(C.byref(p), part._h, C.c_uint32(rank), scene._stream()))
+        return
+    r = part.rects(rank)
+    if not r.empty:
+        scene.trace_final(frame, matrices, frame_count, cfg, tile=(r.final_y0, r.final_h, r.final_x0, r.final_w))
 
 
 def history_exchange_plan(part, motion_halo):
-    """Who sends which reservoir band to whom after a RIS pass: rank r needs the pixels within SPATIAL_HALO + motion_halo
-    of its strip that lie outside strip + SPATIAL_HALO (those it traced itself); every such pixel is owned — and was
-    traced with exact history — by exactly one other rank. Returns a list of (src, dst, start, size) along the axis, in
-    a deterministic order every rank derives alike."""
-    plan = []
-    if motion_halo <= 0 or part.world <= 1:
-        return plan
-    for dst in range(part.world):
-        a0, n = part.span(dst)
-        if n <= 0:
-            continue
-        g0, gn = part.grown(dst, SPATIAL_HALO)
-        h0, hn = part.grown(dst, SPATIAL_HALO + motion_halo)
-        for lo, hi in ((h0, g0), (g0 + gn, h0 + hn)):         # the band before and the band after the traced region
-            for src in range(part.world):
-                if src == dst:
-                    continue
-                s0, sn = part.span(src)
-                x0, x1 = max(lo, s0), min(hi, s0 + sn)
-                if x1 > x0:
-                    plan.append((src, dst, x0, x1 - x0))
-    return plan
+    """Who sends which reservoir band to whom after a RIS pass (sr_history_exchange_plan): rank r needs the pixels within
+    SPATIAL_HALO + motion_halo of its strip that lie outside strip + SPATIAL_HALO (those it traced itself); every such pixel is
+    owned — and was traced with exact history — by exactly one other rank. Returns a list of (src, dst, start, size) along the
+    axis, in a deterministic order every rank derives alike."""
+    import ctypes as C
+    from . import abi
+    from ._lib import check, lib
+    n = C.c_uint32()
+    check(lib().sr_history_exchange_plan(part._h, C.c_uint32(max(int(motion_halo), 0)), None, C.c_uint32(0), C.byref(n)))
+    if n.value == 0:
+        return []
+    buf = (abi.SrStripTransfer * n.value)()
+    check(lib().sr_history_exchange_plan(part._h, C.c_uint32(int(motion_halo)), buf, C.c_uint32(n.value), C.byref(n)))
+    return [(t.src, t.dst, t.start, t.size) for t in buf]
 
 
 def exchange_history(frame, frame_count, part, rank, motion_halo, as_tensor=None):

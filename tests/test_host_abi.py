@@ -29,7 +29,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_struct_sizes_match_header():
-    assert C.sizeof(abi.SrRtParams) == 176 and C.sizeof(abi.SrTraceConfig) == 40 and C.sizeof(abi.SrMatrices) == 256
+    assert C.sizeof(abi.SrRtParams) == 184 and C.sizeof(abi.SrTraceConfig) == 40 and C.sizeof(abi.SrMatrices) == 256
+    assert C.sizeof(abi.SrRayCounters) == 40 and C.sizeof(abi.SrStripRects) == 56 and C.sizeof(abi.SrStripTransfer) == 16
+    assert abi.SrRtParams.primary_payload.offset == 104 and abi.SrRtParams.frame_count.offset == 112
     cfg = abi.SrTraceConfig()
     _lib.lib().sr_trace_config_default(C.byref(cfg))
     ref = abi.SrTraceConfig.reference()
@@ -261,6 +263,69 @@ def test_as_state_heuristic_matches_restatement_and_documented_behaviour():
     for _ in range(18):
         op = L.sr_as_state_next_op(C.byref(st), 0); L.sr_as_state_mark_built(C.byref(st), op); ops.append(op)
     assert ops == [N] * 15 + [S] + [N] * 2 and st.changing == 0
+
+
+def test_strip_partition_and_plans_equal_the_python_originals():
+    """csrc/multi_gpu.cpp (sr_partition_*, sr_balanced_bounds, sr_axis_cost_from_tiles, sr_history_exchange_plan, sr_strip_rects)
+    against the Python implementations of rounds 1-2 (tests/strip_reference.py): world sizes 2, 3, 4, 8, both axes, equal and
+    cost-balanced cuts, motion halos 0 / 7 / 40, on the bench extent and a ragged one; then the error behaviour."""
+    import strip_reference as ref
+    from sunray_amd import distributed as sd
+    rng = np.random.default_rng(11)
+    assert sd.SPATIAL_HALO == ref.SPATIAL_HALO == abi.SPATIAL_HALO == 30
+    for W, H in ((1920, 1080), (203, 77), (64, 4096)):
+        for axis in ("cols", "rows"):
+            length = W if axis == "cols" else H
+            tiles_x, tiles_y = (W + 7) // 8, (H + 7) // 8
+            tile_costs = rng.integers(0, 1 << 20, size=tiles_x * tiles_y).astype(np.float64)
+            tile_costs[rng.random(tile_costs.size) < 0.3] = 0.0                       # sky tiles
+            cost_ref = ref.axis_cost_from_tiles(tile_costs, tiles_x, axis, length)
+            cost = sd.axis_cost_from_tiles(tile_costs, tiles_x, axis, length)
+            assert cost.shape == cost_ref.shape and (cost == cost_ref).all()
+            for world in (2, 3, 4, 8):
+                for min_size, max_share in ((8, 2.5), (32, 2.5), (1, 1.2)):
+                    assert sd.balanced_bounds(cost, world, min_size, max_share) == ref.balanced_bounds(cost_ref, world, min_size, max_share)
+                for bounds in (None, ref.balanced_bounds(cost_ref, world, min_size=sd.SPATIAL_HALO + 2)):
+                    a, b = sd.Partition(W, H, world, axis, bounds), ref.Partition(W, H, world, axis, bounds)
+                    assert a.bounds == b.bounds and a.sizes() == b.sizes() and a.length == b.length
+                    for rank in range(world):
+                        assert a.span(rank) == b.span(rank)
+                        for grow in (0, 30, 37, 70, 5000):
+                            assert a.grown(rank, grow) == b.grown(rank, grow)
+                        a0, n = b.span(rank)
+                        assert a.tile(a0, n) == b.tile(a0, n)
+                        # launch rectangles: RIS over strip + spatial halo with the counting window on the strip, final pass on the strip
+                        r = a.rects(rank)
+                        g0, gn = b.grown(rank, ref.SPATIAL_HALO)
+                        assert (r.ris_y0, r.ris_h, r.ris_x0, r.ris_w) == b.tile(g0, gn) and (r.final_y0, r.final_h, r.final_x0, r.final_w) == b.tile(a0, n)
+                        assert r.empty == (1 if n == 0 else 0) and r.count_window == (1 if n > 0 else 0)
+                        if n > 0:
+                            assert (r.count_x0, r.count_cols, r.count_y0, r.count_rows) == ((a0, n, 0, 0) if axis == "cols" else (0, 0, a0, n))
+                    for motion_halo in (0, 7, 40):
+                        assert sd.history_exchange_plan(a, motion_halo) == ref.history_exchange_plan(b, motion_halo)
+    one = sd.Partition(640, 360, 1, "cols")
+    r = one.rects(0)
+    assert (r.ris_x0, r.ris_w, r.count_window, r.empty) == (0, 640, 0, 0) and sd.history_exchange_plan(one, 40) == []
+    # errors
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.sr_partition_create(C.c_uint32(64), C.c_uint32(64), C.c_uint32(0), C.c_uint32(0), None, C.byref(h)) == -1
+    assert L.sr_partition_create(C.c_uint32(64), C.c_uint32(64), C.c_uint32(2), C.c_uint32(5), None, C.byref(h)) == -1
+    assert L.sr_partition_create(C.c_uint32(64), C.c_uint32(64), C.c_uint32(2), C.c_uint32(0), (C.c_uint32 * 3)(0, 40, 63), C.byref(h)) == -1
+    assert L.sr_partition_create(C.c_uint32(64), C.c_uint32(64), C.c_uint32(2), C.c_uint32(0), (C.c_uint32 * 3)(0, 70, 64), C.byref(h)) == -1
+    with pytest.raises(ValueError):
+        sd.Partition(64, 64, 2, "diag")
+    with pytest.raises(ValueError):
+        sd.Partition(64, 64, 2, "cols", [0, 10])
+    p = sd.Partition(64, 64, 2)
+    a, n = C.c_uint32(), C.c_uint32()
+    assert L.sr_partition_span(p._h, C.c_uint32(2), C.c_uint32(0), C.byref(a), C.byref(n)) == -1
+    cnt = C.c_uint32()
+    assert L.sr_history_exchange_plan(p._h, C.c_uint32(4), None, C.c_uint32(3), C.byref(cnt)) == -1       # out == NULL with cap > 0
+    assert L.sr_history_exchange_plan(p._h, C.c_uint32(4), None, C.c_uint32(0), C.byref(cnt)) == 0 and cnt.value == 2
+    out = (C.c_uint32 * 3)()
+    assert L.sr_balanced_bounds((C.c_double * 4)(1.0, float("nan"), 1.0, 1.0), C.c_uint32(4), C.c_uint32(2), C.c_uint32(1), C.c_double(2.5), out) == -1
+    assert L.sr_balanced_bounds(None, C.c_uint32(4), C.c_uint32(2), C.c_uint32(1), C.c_double(2.5), out) == -1
 
 
 def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
