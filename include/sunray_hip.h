@@ -41,7 +41,7 @@ typedef enum SrStatus {
     SR_ERR_HIP = -2,         /* ErrorSource::Vulkan counterpart: a HIP runtime call failed            */
     SR_ERR_OOM = -3,         /* ErrorSource::GpuAllocator                                            */
     SR_ERR_STATE = -4,       /* ErrorSource::RenderGraph: call order violated (e.g. trace before build) */
-    SR_ERR_UNSUPPORTED = -5  /* input outside the built scope (16-bit images, CMYK JPEG, sparse accessors, > 2^28 triangles) */
+    SR_ERR_UNSUPPORTED = -5  /* input outside the built scope (16-bit images, CMYK JPEG, > 2^28 triangles) */
 } SrStatus;
 
 #define SR_NULL_TEXTURE 0xFFFFFFFFu /* rt_types.slang:192, resources/material.rs:49 */
@@ -544,7 +544,8 @@ int sr_renderer_render_to_host_memory(SrRenderer* renderer, const float cam_pos[
  * Scene::load_into_gpu (scene.rs:52-176). `.glb` or `.gltf` (+ external / data: buffers); images: 8-bit PNG and JPEG
  * (baseline, extended sequential, progressive; what `gltf::import` hands on as R8 / RG8 / RGB8 / RGBA8; JPEG texels are
  * decoder-defined within a few units: parity unpinned, csrc/jpeg_decode.cpp). 16-bit PNG (the reference stops there too,
- * image/mod.rs:98-104), CMYK / arithmetic-coded JPEG, sparse accessors, camera/light nodes -> SR_ERR_UNSUPPORTED. No device needed. */
+ * image/mod.rs:98-104), CMYK / arithmetic-coded JPEG, camera/light nodes -> SR_ERR_UNSUPPORTED. Sparse accessors are resolved
+ * (zeros or the bufferView, with `count` elements substituted), as the gltf crate's readers do. No device needed. */
 typedef struct SrGltf SrGltf;
 /* The loader's image decoder on its own: extent + channels, and the pixels when `pixels` != NULL (cap >= w*h*channels). */
 int sr_decode_image(const uint8_t* data, size_t n, uint32_t* width, uint32_t* height, uint32_t* channels, uint8_t* pixels, size_t cap);
