@@ -346,6 +346,19 @@ int sr_scene_end_frame(SrScene* scene);
  * SR_OP_FAST_BUILD = device LBVH build, SR_OP_UPDATE = in-place update if the layout allows) instead of the
  * heuristic's choice. The heuristic state is still advanced with the op performed. */
 int sr_scene_force_next_op(SrScene* scene, uint32_t op);
+/* Form of the acceleration structure. The reference instances BLASes through a TLAS (tlas.rs:155-191, resource_manager.rs:236-251).
+ * SR_INSTANCING_FLAT copies every instance's triangles into ONE world-space tree (no ray transform in the walk, work stealing inside the
+ * wave; memory and update cost grow with instances x triangles); SR_INSTANCING_TWO_LEVEL keeps one tree per mesh in object space plus a
+ * top-level tree over the instances (a changed instance list costs a top-level rebuild whatever the meshes hold; the walk transforms
+ * the ray per instance). Both answer every query with the same bits: in the two-level walk the object-space ray only steers box
+ * culling, triangles are tested in world space. SR_INSTANCING_AUTO (default): two-level where the flattened copy would exceed 2^24
+ * triangles and at least four times the meshes' own, or 2^28 in any case. Takes effect at the next sr_scene_set_instances.
+ * SR_INSTANCING = flat | two_level | auto in the environment sets the initial mode. */
+#define SR_INSTANCING_AUTO 0u
+#define SR_INSTANCING_FLAT 1u
+#define SR_INSTANCING_TWO_LEVEL 2u
+int sr_scene_set_instancing(SrScene* scene, uint32_t mode);
+int sr_scene_instancing(const SrScene* scene, uint32_t* mode, uint32_t* two_level_now);
 /* Node layout of the quantised wide BVH this build uses (csrc/bvh_layout.h): children per node, dwords per node, first
  * plane dword, first child dword. */
 int sr_bvh_layout(uint32_t* width, uint32_t* node_dwords, uint32_t* plane_offset, uint32_t* child_offset);

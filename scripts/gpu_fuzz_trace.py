@@ -61,7 +61,10 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     brute = desc.n_triangles() <= 5000
     osc.set_brute_force(brute)
     rays = rays_for(rng, desc, osc, 40000 if brute else 200000, scale)
-    for mode in ("sah", "lbvh", "update"):
+    for mode in ("sah", "lbvh", "update", "two_level"):
+        if mode == "two_level":              # a tree per mesh in object space + a top-level tree over the instances
+            gsc.set_instancing("two_level"); gsc.set_instances(desc.instances)
+            assert gsc.two_level()
         if mode == "lbvh":
             gsc.force_next_op(abi.OP_FAST_BUILD); gsc.set_instances(desc.instances)
         if mode == "update":

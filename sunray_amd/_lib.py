@@ -23,7 +23,7 @@ SYMBOLS = [
     "sr_scene_read_tile_row_costs", "sr_scene_read_tile_costs", "sr_scene_reset_counters", "sr_scene_read_counters", "sr_scene_set_instrumented", "sr_scene_enable_timing",
     "sr_scene_read_timing",
     "sr_partition_create", "sr_partition_destroy", "sr_partition_get", "sr_partition_span", "sr_balanced_bounds", "sr_axis_cost_from_tiles",
-    "sr_history_exchange_plan", "sr_strip_rects", "sr_strip_trace_ris", "sr_strip_trace_final",
+    "sr_history_exchange_plan", "sr_strip_rects", "sr_strip_trace_ris", "sr_strip_trace_final", "sr_scene_set_instancing", "sr_scene_instancing",
 ]
 
 

@@ -122,6 +122,27 @@ struct SrScene {
     std::vector<SrSamplerDesc> samplers;    // sampler slot order (Material::*_sampler)
     DeviceBuffer d_nodes, d_tris, d_shade, d_mesh_const, d_slot_of_gid, d_instances, d_lights, d_misc;
     DeviceBuffer d_shade_tex, d_mesh_tex, d_textures;
+    // two-level form (optional): one tree per mesh in object space (built once per mesh, kept on the host until the set of
+    // meshes changes) + a top-level tree over the instances, rebuilt from the instance list — nothing here scales with
+    // instances x triangles
+    struct HostBlas {
+        bool valid = false;
+        std::vector<uint32_t> nodes;        // 4-wide quantised tree, references local to the mesh
+        std::vector<float> tris, shade, shade_tex;   // 12 / 12 / 24 floats per triangle, leaf order
+        std::vector<uint32_t> slot_of_prim;
+        uint32_t n_tris = 0, n_nodes = 0, max_stack = 0, max_depth = 0;
+        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};   // root box, object space
+        float max_edge_sum = 0.0f, max_abs_vertex = 0.0f;
+        double build_ms = 0.0;
+    };
+    std::vector<HostBlas> blases;           // by mesh slot
+    std::vector<uint32_t> blas_node_base, blas_tri_base;   // of the concatenated device arrays, by mesh slot
+    bool blas_device_current = false;       // the concatenated arrays match the current set of meshes
+    bool any_textured_tl = false;
+    uint32_t blas_stack = 0;
+    DeviceBuffer d_blas_nodes, d_tl_inst, d_tl_instances;
+    int instancing = SR_INSTANCING_AUTO;    // sr_scene_set_instancing / SR_INSTANCING in the environment
+    bool two_level = false;                 // form of the structure that is built right now
     // acceleration-structure maintenance (update in place): per-level node lists, exact node boxes, flatten inputs
     DeviceBuffer d_level_nodes, d_node_box, d_mesh_infos, d_flat_instances, d_scratch;
     // cost-ordered tile schedules of the two passes (kernels.hip thread_pixel), one per launch geometry
@@ -233,6 +254,7 @@ int sr_scene_create(int device, SrScene** out) {
     SrScene* s = new SrScene();
     s->device = device;
     if (const char* ev = getenv("SR_TILE_SCHEDULING")) s->tile_scheduling = atoi(ev) != 0;
+    if (const char* ev = getenv("SR_INSTANCING")) s->instancing = !strcmp(ev, "two_level") ? SR_INSTANCING_TWO_LEVEL : (!strcmp(ev, "flat") ? SR_INSTANCING_FLAT : SR_INSTANCING_AUTO);
     if (const char* ev = getenv("SR_FAST_BUILD")) s->fast_build_ploc = !strcmp(ev, "lbvh") ? 0 : (!strncmp(ev, "ploc", 4) && atoi(ev + 4) > 0 ? atoi(ev + 4) : 16);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
@@ -254,6 +276,7 @@ int sr_scene_destroy(SrScene* s) {
     s->d_level_nodes.release(); s->d_node_box.release(); s->d_mesh_infos.release(); s->d_flat_instances.release(); s->d_scratch.release();
     s->d_nodes.release(); s->d_tris.release(); s->d_shade.release(); s->d_mesh_const.release(); s->d_slot_of_gid.release(); s->d_instances.release();
     s->d_lights.release(); s->d_misc.release();
+    s->d_blas_nodes.release(); s->d_tl_inst.release(); s->d_tl_instances.release();
     for (auto& ts : s->schedules) { ts.cost.release(); ts.order.release(); }
     for (auto& pool : s->events) for (auto& e : pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete s;
@@ -331,6 +354,9 @@ int sr_scene_add_blas(SrScene* s, uint64_t key, const SrVertex* vertices, uint32
     }
     s->slots[key] = slot;
     s->built = false;
+    if (s->blases.size() < s->meshes.size()) s->blases.resize(s->meshes.size());
+    s->blases[slot] = SrScene::HostBlas();
+    s->blas_device_current = false;
     if (out_slot) *out_slot = slot;
     return SR_OK;
 }
@@ -363,6 +389,8 @@ int sr_scene_remove(SrScene* s, uint64_t key) {
     if (m.d_indices) (void)hipFree(m.d_indices);
     for (uint32_t es : m.emissive_slots) s->free_emissive_slots.push_back(es);
     m = srh::HostMesh();
+    if (slot < s->blases.size()) s->blases[slot] = SrScene::HostBlas();
+    s->blas_device_current = false;
     s->free_mesh_slots.push_back(slot);
     s->slots.erase(it);
     s->built = false;
@@ -526,6 +554,246 @@ int update_in_place(SrScene* s) {
 
 int full_build(SrScene* s);
 
+// ---- two-level form -------------------------------------------------------------------------------------------------
+// The reference instances BLASes through a TLAS it rebuilds or updates every frame (tlas.rs:155-191,
+// resource_manager.rs:236-251). The one-level form copies every instance's triangles into one world-space tree — memory and
+// update cost O(instances x triangles). This form keeps one tree per MESH in object space and a top-level tree over padded
+// instance boxes: a changed instance list costs a top-level rebuild (host, O(instances log instances)) and one 128-byte record
+// per instance, whatever the meshes hold. Hits are those of the one-level form bit for bit (traverse.h: traverse_tl).
+constexpr uint32_t kTlStackCap = 60;     // LDS stack entries a two-level walk may need (top-level + marker + mesh tree)
+
+uint32_t depth_for(uint64_t n_items) {   // binary depth that lets the builder reach leaves of <= 2 items with slack for SAH splits
+    uint32_t need = 2;
+    for (uint64_t c = (n_items + 1) / 2; c > 1; c = (c + 1) / 2) need++;
+    return std::max(6u, std::min((uint32_t)srd::kMaxBinaryDepth, need + 6u));
+}
+
+// Object-space tree of one mesh (OpType::SlowBuild of a BLAS, blas.rs:178): same builder, same triangle padding.
+int build_blas(SrScene* s, uint32_t slot) {
+    const srh::HostMesh& mesh = s->meshes[slot];
+    SrScene::HostBlas& b = s->blases[slot];
+    const uint32_t n = mesh.n_indices / 3;
+    std::vector<srh::BuildTri> tris(n);
+    float max_edge = 0.0f, max_abs = 0.0f;
+    for (uint32_t p = 0; p < n; p++) {
+        const float* v[3];
+        for (int j = 0; j < 3; j++) v[j] = mesh.vertices[mesh.indices[3 * p + j]].position;
+        srh::BuildTri& t = tris[p];
+        for (int a = 0; a < 3; a++) {
+            t.v0[a] = v[0][a]; t.e1[a] = v[1][a] - v[0][a]; t.e2[a] = v[2][a] - v[0][a];
+            max_edge = std::max(max_edge, std::fabs(t.e1[a]) + std::fabs(t.e2[a]));
+            for (int j = 0; j < 3; j++) max_abs = std::max(max_abs, std::fabs(v[j][a]));
+        }
+        t.prim = p; t.inst = 0; t.gid = p;
+    }
+    srh::BvhResult bvh;
+    srh::build_bvh(tris, depth_for(n), bvh);
+    b.nodes.swap(bvh.nodes);
+    b.n_tris = n; b.n_nodes = bvh.n_nodes; b.max_stack = bvh.max_stack; b.max_depth = bvh.max_depth; b.build_ms = bvh.build_ms;
+    b.max_edge_sum = max_edge; b.max_abs_vertex = max_abs;
+    b.tris.assign((size_t)n * 12, 0.0f);
+    b.shade.assign((size_t)n * 12, 0.0f);
+    b.slot_of_prim.assign(n ? n : 1, 0u);
+    const bool textured = [&] { const uint32_t* tex = &mesh.material.base_color_image; for (int i = 0; i < 10; i += 2) if (tex[i] != SR_NULL_TEXTURE) return true; return false; }();
+    if (textured) b.shade_tex.assign((size_t)n * 24, 0.0f); else b.shade_tex.clear();
+    for (int a = 0; a < 3; a++) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+    for (uint32_t sl = 0; sl < n; sl++) {
+        const uint32_t p = bvh.order[sl];
+        const SrVertex* v[3];
+        for (int j = 0; j < 3; j++) v[j] = &mesh.vertices[mesh.indices[3 * p + j]];
+        float* q = &b.tris[(size_t)sl * 12];
+        for (int j = 0; j < 3; j++) memcpy(q + 3 * j, v[j]->position, 12);          // object-space v0, v1, v2
+        memcpy(q + 9, &p, 4);                                                       // primitive index
+        float* sh = &b.shade[(size_t)sl * 12];
+        for (int j = 0; j < 3; j++) memcpy(sh + 3 * j, v[j]->normal, 12);
+        memcpy(sh + 10, &slot, 4);                                                  // mesh slot; the instance comes from the walk
+        if (textured) {
+            float* tx = &b.shade_tex[(size_t)sl * 24];
+            for (int j = 0; j < 3; j++) { memcpy(tx + 2 * j, v[j]->base_color_tex_coord, 8); memcpy(tx + 6 + 2 * j, v[j]->normal_tex_coord, 8); }
+            memcpy(tx + 12, v[0]->tangent, 12);
+            tx[15] = v[0]->tangent[3] >= 0.0f ? 1.0f : -1.0f;
+            memcpy(tx + 16, v[1]->tangent, 12);
+            memcpy(tx + 19, v[2]->tangent, 12);
+        }
+        b.slot_of_prim[p] = sl;
+        const srh::BuildTri& t = tris[p];
+        for (int a = 0; a < 3; a++) {                                               // the padded triangle box, as the builder bounds it
+            const float pad = 4e-6f * (std::fabs(t.e1[a]) + std::fabs(t.e2[a]));
+            const float lo = std::min(v[0]->position[a], std::min(v[1]->position[a], v[2]->position[a])) - pad;
+            const float hi = std::max(v[0]->position[a], std::max(v[1]->position[a], v[2]->position[a])) + pad;
+            b.lo[a] = std::min(b.lo[a], std::nextafter(lo, -INFINITY)); b.hi[a] = std::max(b.hi[a], std::nextafter(hi, INFINITY));
+        }
+    }
+    b.valid = true;
+    return SR_OK;
+}
+
+// Every live mesh's tree, triangle, shade and primitive -> slot records, one after the other, on the device.
+int upload_blases(SrScene* s) {
+    int rc;
+    const size_t nm = s->meshes.size();
+    s->blases.resize(nm);
+    s->blas_node_base.assign(nm, 0u); s->blas_tri_base.assign(nm, 0u);
+    uint64_t n_nodes = 0, n_tris = 0;
+    s->any_textured_tl = false; s->blas_stack = 0;
+    for (size_t m = 0; m < nm; m++) {
+        if (s->meshes[m].n_vertices == 0) continue;
+        if (!s->blases[m].valid && (rc = build_blas(s, (uint32_t)m)) != SR_OK) return rc;
+        s->blas_node_base[m] = (uint32_t)n_nodes; s->blas_tri_base[m] = (uint32_t)n_tris;
+        n_nodes += s->blases[m].n_nodes; n_tris += s->blases[m].n_tris;
+        s->any_textured_tl = s->any_textured_tl || !s->blases[m].shade_tex.empty();
+        s->blas_stack = std::max(s->blas_stack, s->blases[m].max_stack);
+    }
+    if (n_tris >= (1ull << 28) || n_nodes >= (1ull << 31)) return fail(SR_ERR_UNSUPPORTED, "the meshes together exceed 2^28 triangles (leaf reference encoding)");
+    std::vector<uint32_t> nodes((size_t)n_nodes * srl::kNodeDwords);
+    std::vector<float> tris((size_t)n_tris * 12), shade((size_t)n_tris * 12), shade_tex(s->any_textured_tl ? (size_t)n_tris * 24 : 0);
+    std::vector<uint32_t> slot_of_prim(n_tris ? n_tris : 1, 0u);
+    for (size_t m = 0; m < nm; m++) {
+        if (s->meshes[m].n_vertices == 0) continue;
+        const SrScene::HostBlas& b = s->blases[m];
+        const uint32_t nb = s->blas_node_base[m], tb = s->blas_tri_base[m];
+        for (uint32_t i = 0; i < b.n_nodes; i++) {
+            uint32_t* q = &nodes[((size_t)nb + i) * srl::kNodeDwords];
+            memcpy(q, &b.nodes[(size_t)i * srl::kNodeDwords], srl::kNodeBytes);
+            for (int c = 0; c < srl::kBvhWidth; c++) {                               // references become global
+                const int ref = (int)q[srl::kChildOffset + c];
+                if (ref >= 0) q[srl::kChildOffset + c] = (uint32_t)(ref + (int)nb);
+                else { const uint32_t lv = ~(uint32_t)ref; const uint32_t cnt = lv & 7u; if (cnt) q[srl::kChildOffset + c] = ~((((lv >> 3) + tb) << 3) | cnt); }
+            }
+        }
+        if (b.n_tris) {
+            memcpy(&tris[(size_t)tb * 12], b.tris.data(), (size_t)b.n_tris * 48);
+            memcpy(&shade[(size_t)tb * 12], b.shade.data(), (size_t)b.n_tris * 48);
+            if (!b.shade_tex.empty()) memcpy(&shade_tex[(size_t)tb * 24], b.shade_tex.data(), (size_t)b.n_tris * 96);
+            for (uint32_t p = 0; p < b.n_tris; p++) slot_of_prim[(size_t)tb + p] = tb + b.slot_of_prim[p];
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if ((rc = s->d_blas_nodes.upload(nodes.data(), nodes.size() * 4)) != SR_OK) return rc;
+    if ((rc = s->d_tris.upload(tris.data(), tris.size() * 4)) != SR_OK) return rc;
+    if ((rc = s->d_shade.upload(shade.data(), shade.size() * 4)) != SR_OK) return rc;
+    if (s->any_textured_tl) { if ((rc = s->d_shade_tex.upload(shade_tex.data(), shade_tex.size() * 4)) != SR_OK) return rc; }
+    else s->d_shade_tex.release();
+    if ((rc = s->d_slot_of_gid.upload(slot_of_prim.data(), slot_of_prim.size() * 4)) != SR_OK) return rc;
+    s->blas_device_current = true;
+    return SR_OK;
+}
+
+int two_level_build(SrScene* s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    if (!s->blas_device_current || !s->two_level) { if ((rc = upload_blases(s)) != SR_OK) return rc; }
+    bool any_textured = false;
+    if ((rc = upload_mesh_tables(s, &any_textured)) != SR_OK) return rc;
+    // instance records + padded world-space boxes
+    const size_t ni = s->fid.instances.size();
+    std::vector<srd::DevTlInstance> recs(ni ? ni : 1);
+    memset(recs.data(), 0, recs.size() * sizeof(srd::DevTlInstance));
+    std::vector<srh::BuildBox> boxes;
+    std::vector<uint32_t> box_inst;           // instances with a box (a singular transform collapses every triangle: no hit is possible)
+    boxes.reserve(ni); box_inst.reserve(ni);
+    const double eps = std::ldexp(1.0, -24);
+    for (size_t i = 0; i < ni; i++) {
+        const srh::HostInstance& in = s->fid.instances[i];
+        const SrScene::HostBlas& b = s->blases[in.mesh_slot];
+        srd::DevTlInstance& r = recs[i];
+        const float* M = in.o2w.m;
+        memcpy(r.o2w, M, 48);
+        r.blas_root = s->blas_node_base[in.mesh_slot];
+        r.tri_offset = in.tri_offset;
+        r.mesh_slot = in.mesh_slot;
+        r.prim_base = s->blas_tri_base[in.mesh_slot];
+        // inverse of the affine transform, in double
+        const double a00 = M[0], a01 = M[1], a02 = M[2], a10 = M[4], a11 = M[5], a12 = M[6], a20 = M[8], a21 = M[9], a22 = M[10];
+        const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+        const double det = a00 * c00 + a01 * c01 + a02 * c02;
+        if (b.n_tris == 0 || !(std::fabs(det) > 0.0) || !std::isfinite(1.0 / det)) continue;
+        const double id = 1.0 / det;
+        const double R[9] = {c00 * id, (a02 * a21 - a01 * a22) * id, (a01 * a12 - a02 * a11) * id,
+                             c01 * id, (a00 * a22 - a02 * a20) * id, (a02 * a10 - a00 * a12) * id,
+                             c02 * id, (a01 * a20 - a00 * a21) * id, (a00 * a11 - a01 * a10) * id};
+        const double T[3] = {M[3], M[7], M[11]};
+        double r_norm = 0.0, m_norm = 0.0, t_max = 0.0;
+        bool finite = true;
+        for (int row = 0; row < 3; row++) {
+            for (int c = 0; c < 3; c++) r.w2o[4 * row + c] = (float)R[3 * row + c];
+            r.w2o[4 * row + 3] = (float)(-(R[3 * row] * T[0] + R[3 * row + 1] * T[1] + R[3 * row + 2] * T[2]));
+            r_norm = std::max(r_norm, std::fabs(R[3 * row]) + std::fabs(R[3 * row + 1]) + std::fabs(R[3 * row + 2]));
+            m_norm = std::max(m_norm, std::fabs((double)M[4 * row]) + std::fabs((double)M[4 * row + 1]) + std::fabs((double)M[4 * row + 2]));
+            t_max = std::max(t_max, std::fabs(T[row]));
+            for (int c = 0; c < 4; c++) finite = finite && std::isfinite(r.w2o[4 * row + c]);
+        }
+        if (!finite) continue;
+        // world box: the 8 corners of the mesh's (already padded) box, then padding for the rounding of the transformed vertices
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, p_max = 0.0;
+        for (int corner = 0; corner < 8; corner++) {
+            const double x = (corner & 1) ? b.hi[0] : b.lo[0], y = (corner & 2) ? b.hi[1] : b.lo[1], z = (corner & 4) ? b.hi[2] : b.lo[2];
+            for (int row = 0; row < 3; row++) {
+                const double w = (double)M[4 * row] * x + (double)M[4 * row + 1] * y + (double)M[4 * row + 2] * z + (double)M[4 * row + 3];
+                lo[row] = std::min(lo[row], w); hi[row] = std::max(hi[row], w);
+                p_max = std::max(p_max, std::fabs(w));
+            }
+        }
+        const double pad_w = 64.0 * eps * (p_max + m_norm * b.max_abs_vertex + t_max) + 8e-6 * m_norm * b.max_edge_sum;
+        srh::BuildBox bx;
+        for (int a = 0; a < 3; a++) { bx.lo[a] = std::nextafter((float)(lo[a] - pad_w), -INFINITY); bx.hi[a] = std::nextafter((float)(hi[a] + pad_w), INFINITY); }
+        // widening of the mesh's object-space boxes: rounding of the ray transform (grows with the ray origin) and of the world-space
+        // vertices, plus the barycentric slack of the world-space triangle test seen from object space
+        r.pad_a = (float)(64.0 * eps * r_norm);
+        r.pad_b = (float)(r_norm * (64.0 * eps * (p_max + t_max + m_norm * b.max_abs_vertex) + 8e-6 * m_norm * b.max_edge_sum));
+        boxes.push_back(bx);
+        box_inst.push_back((uint32_t)i);
+    }
+    srh::BvhResult tl;
+    srh::build_bvh_boxes(boxes, depth_for(boxes.size()), tl);
+    std::vector<uint32_t> tl_inst(tl.order.size() ? tl.order.size() : 1, 0u);
+    for (size_t k = 0; k < tl.order.size(); k++) tl_inst[k] = box_inst[tl.order[k]];
+    const uint32_t need = tl.max_stack + srl::kLeafMax + s->blas_stack + 1u;     // top-level entries + pending instances of a leaf + marker + mesh tree
+    if (need > kTlStackCap) return fail(SR_ERR_STATE, "two-level structure needs a deeper traversal stack than the kernels provide");
+    HIP_TRY(hipDeviceSynchronize());
+    if ((rc = upload_instance_tables(s)) != SR_OK) return rc;
+    if ((rc = s->d_nodes.upload(tl.nodes.data(), tl.nodes.size() * 4)) != SR_OK) return rc;
+    if ((rc = s->d_tl_inst.upload(tl_inst.data(), tl_inst.size() * 4)) != SR_OK) return rc;
+    if ((rc = s->d_tl_instances.upload(recs.data(), recs.size() * sizeof(srd::DevTlInstance))) != SR_OK) return rc;
+    s->dev.nodes = (const float4*)s->d_nodes.p;
+    s->dev.blas_nodes = (const float4*)s->d_blas_nodes.p;
+    s->dev.tl_inst = (const uint32_t*)s->d_tl_inst.p;
+    s->dev.tl_instances = (const srd::DevTlInstance*)s->d_tl_instances.p;
+    s->dev.tris = (const float4*)s->d_tris.p;
+    s->dev.shade = (const float4*)s->d_shade.p;
+    s->dev.shade_tex = (const float4*)s->d_shade_tex.p;
+    s->dev.slot_of_gid = (const uint32_t*)s->d_slot_of_gid.p;
+    s->dev.counters = (unsigned long long*)s->d_misc.p;
+    s->dev.n_tris = s->fid.n_triangles;
+    uint64_t blas_nodes = 0, blas_tris = 0;
+    for (size_t m = 0; m < s->meshes.size(); m++) if (s->meshes[m].n_vertices) { blas_nodes += s->blases[m].n_nodes; blas_tris += s->blases[m].n_tris; }
+    s->stats.n_triangles = s->fid.n_triangles;
+    s->stats.n_nodes = tl.n_nodes + blas_nodes;
+    s->stats.node_bytes = s->stats.n_nodes * srl::kNodeBytes;
+    s->stats.tri_bytes = blas_tris * 48;
+    s->stats.max_depth = tl.max_depth;
+    s->stats.max_stack = need;
+    s->stack_entries = (int)((std::max(need, 3u) + 1u + 3u) & ~3u);
+    s->stats.sah_cost = tl.sah_cost;
+    s->stats.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    s->shape.clear();
+    s->built = true;
+    s->two_level = true;
+    s->last_build_on_device = false;
+    return SR_OK;
+}
+
+// The form this instance list is built in: on request, or (auto) where instancing really shares geometry and the flattened copy
+// would be large — more than 2^24 flattened triangles and at least four times the meshes' own.
+bool wants_two_level(const SrScene* s) {
+    if (s->instancing == SR_INSTANCING_TWO_LEVEL) return true;
+    if (s->instancing == SR_INSTANCING_FLAT) return false;
+    uint64_t own = 0;
+    std::vector<char> seen(s->meshes.size(), 0);
+    for (const auto& in : s->fid.instances) if (!seen[in.mesh_slot]) { seen[in.mesh_slot] = 1; own += s->meshes[in.mesh_slot].n_indices / 3; }
+    return s->fid.n_triangles > (1u << 24) && (uint64_t)s->fid.n_triangles >= 4ull * own;
+}
+
 // OpType::FastBuild: linear BVH built on the device (bvh_gpu.hip). Falls back to the host builder for small scenes
 // and for trees that would need a deeper traversal stack than one workgroup's LDS share.
 constexpr uint32_t kDeviceBuildMinTris = 4096;
@@ -603,8 +871,9 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
         if (it != s->slots.end()) n_tri += (uint64_t)counts[k] * (s->meshes[it->second].n_indices / 3);
     }
     if (n_inst && !transforms) return fail(SR_ERR_INVALID_ARG, "frame_instance_data: transforms is null but instances were given");
-    if (n_tri >= (1ull << 28)) return fail(SR_ERR_UNSUPPORTED, "scene exceeds 2^28 triangles (leaf reference encoding)");
-    if (n_inst >= (1ull << 31)) return fail(SR_ERR_UNSUPPORTED, "scene exceeds 2^31 instances");
+    if (n_tri >= 0xFFFFFFFFull) return fail(SR_ERR_UNSUPPORTED, "scene exceeds 2^32 - 1 triangles (32-bit global triangle index)");
+    if (n_tri >= (1ull << 28) && s->instancing == SR_INSTANCING_FLAT) return fail(SR_ERR_UNSUPPORTED, "scene exceeds 2^28 triangles (leaf reference encoding of the one-level form)");
+    if (n_inst >= (1ull << 28)) return fail(SR_ERR_UNSUPPORTED, "scene exceeds 2^28 instances");
     for (uint64_t i = 0; i < n_inst; i++)
         for (int c = 0; c < 12; c++)
             if (!std::isfinite(transforms[i].m[c])) return fail(SR_ERR_INVALID_ARG, "frame_instance_data: instance transform holds a non-finite value");
@@ -613,10 +882,27 @@ int sr_scene_set_instances(SrScene* s, const uint64_t* keys, const uint32_t* cou
     std::string err;
     srh::FrameInstanceData fid;
     if (!srh::frame_instance_data(s->meshes, s->slots, keys, counts, n_keys, transforms, fid, err)) return fail(SR_ERR_INVALID_ARG, err);
-    if (fid.n_triangles >= (1u << 28)) return fail(SR_ERR_UNSUPPORTED, "scene exceeds 2^28 triangles (leaf reference encoding)");
     s->fid = std::move(fid);
     s->emissive_table = s->emissive_tris;
     if (s->emissive_table.empty()) { SrEmissiveTriangle z; memset(&z, 0, sizeof(z)); s->emissive_table.push_back(z); }
+    // Two-level form (a tree per mesh + a top-level tree over the instances): on request or where the flattened copy would be
+    // large. A changed instance list is then a top-level rebuild, reported as a fast build (Tlas::queue_build rebuilds in kind).
+    if (wants_two_level(s) || s->fid.n_triangles >= (1u << 28)) {
+        const uint32_t op = s->built_once ? SR_OP_FAST_BUILD : SR_OP_SLOW_BUILD;
+        s->forced_op = SR_OP_NONE;
+        if (!s->two_level) s->built = false;
+        rc = two_level_build(s);
+        if (rc != SR_OK) { s->built = false; return rc; }
+        if (s->built_once) srh::as_state_mark_built(s->as_state, op);
+        s->built_once = true;
+        s->last_op = op;
+        return SR_OK;
+    }
+    if (s->two_level) {                       // back to the one-level form: everything is rebuilt
+        s->two_level = false; s->built = false;
+        s->dev.blas_nodes = nullptr; s->dev.tl_inst = nullptr; s->dev.tl_instances = nullptr;
+        s->forced_op = s->forced_op == SR_OP_NONE ? SR_OP_SLOW_BUILD : s->forced_op;
+    }
     // Tlas::queue_build (tlas.rs:155-191): the instance data is new, so the heuristic is asked with inputs_changed =
     // true; an UPDATE needs the same instance layout (here: the same mesh per instance and unchanged meshes),
     // anything else is a rebuild. The very first build is the quality build (Tlas::new).
@@ -644,10 +930,22 @@ int sr_scene_end_frame(SrScene* s) {
     if (op == SR_OP_SLOW_BUILD) {
         int rc = bind_device(s);
         if (rc != SR_OK) return rc;
-        if ((rc = full_build(s)) != SR_OK) { s->built = false; return rc; }
+        if ((rc = s->two_level ? two_level_build(s) : full_build(s)) != SR_OK) { s->built = false; return rc; }
     }
     srh::as_state_mark_built(s->as_state, op);
     s->last_op = op;
+    return SR_OK;
+}
+
+int sr_scene_set_instancing(SrScene* s, uint32_t mode) {
+    if (!s || mode > SR_INSTANCING_TWO_LEVEL) return fail(SR_ERR_INVALID_ARG, "sr_scene_set_instancing: bad argument");
+    s->instancing = (int)mode;
+    return SR_OK;
+}
+int sr_scene_instancing(const SrScene* s, uint32_t* mode, uint32_t* two_level_now) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_instancing: scene is null");
+    if (mode) *mode = (uint32_t)s->instancing;
+    if (two_level_now) *two_level_now = (s->built && s->two_level) ? 1u : 0u;
     return SR_OK;
 }
 
@@ -678,6 +976,7 @@ int sr_bvh_layout(uint32_t* width, uint32_t* node_dwords, uint32_t* plane_offset
 
 int sr_scene_read_bvh(const SrScene* s, uint32_t* nodes_out, float* tris_out) {
     if (!s || !s->built) return fail(SR_ERR_STATE, "sr_scene_read_bvh: scene not built");
+    if (s->two_level) return fail(SR_ERR_UNSUPPORTED, "sr_scene_read_bvh: the scene is built in the two-level form");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipDeviceSynchronize());
     if (nodes_out) HIP_TRY(hipMemcpy(nodes_out, s->d_nodes.p, (size_t)s->stats.n_nodes * srl::kNodeBytes, hipMemcpyDeviceToHost));
@@ -818,7 +1117,7 @@ static int trace_queue(SrScene* s, const SrRay* rays, uint32_t n, SrHit* hits, u
     if (const char* e = getenv("SR_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));   // tuning switch
     const int n_blocks = s->n_cus * per_cu;
     ScopedTiming tm(s, any ? kAny : kClosest, st);
-    int e = srk_launch_trace(s->dev, rays, n, hits, occluded, queue_head, any, s->instrumented, n_blocks, s->stack_entries, st);
+    int e = srk_launch_trace(s->dev, rays, n, hits, occluded, queue_head, any, s->instrumented, s->two_level ? 1 : 0, n_blocks, s->stack_entries, st);
     if (e != 0) return fail(SR_ERR_HIP, std::string("trace kernel launch: ") + hipGetErrorString((hipError_t)e));
     return SR_OK;
 }
@@ -925,7 +1224,7 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
     PassLabel label(name);
     {
         ScopedTiming tm(s, which == 0 ? kRis : kFinal, st);      // times the pass kernel only
-        e = srk_launch_pass(a, which, s->instrumented, s->dev.shade_tex != nullptr, s->stack_entries, st);
+        e = srk_launch_pass(a, which, s->instrumented, s->dev.shade_tex != nullptr, s->two_level ? 1 : 0, s->stack_entries, st);
     }
     if (e != 0) return fail(SR_ERR_HIP, std::string(name) + " launch: " + hipGetErrorString((hipError_t)e));
     // The schedule changes rarely (it follows where the expensive rows and columns are): re-derive it after the first launches

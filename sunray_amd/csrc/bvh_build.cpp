@@ -41,7 +41,6 @@ constexpr uint32_t kLeafMax = srl::kLeafMax;
 constexpr uint32_t kParallelMin = 1u << 15;
 
 struct Builder {
-    const std::vector<BuildTri>& tris;
     std::vector<Aabb> bounds;
     std::vector<float> centroid[3];
     std::vector<uint32_t> order;
@@ -54,7 +53,7 @@ struct Builder {
         double cost = 0.0;
     };
 
-    explicit Builder(const std::vector<BuildTri>& t, uint32_t md) : tris(t), max_depth(md) {}
+    explicit Builder(uint32_t md) : max_depth(md) {}
 
     static int leaf_ref(uint32_t first, uint32_t count) { return (int)~((first << 3) | count); }
 
@@ -392,10 +391,35 @@ void flatten_instances(const std::vector<HostMesh>& meshes, const FrameInstanceD
     }
 }
 
+namespace {
+// Tree over the boxes already in b.bounds / b.centroid / b.order: binned-SAH binary tree, then the 4-wide collapse.
+void build_core(Builder& b, uint32_t n, const Aabb& root, uint32_t max_depth, BvhResult& res) {
+    b.root_area = std::max((double)root.half_area(), 1e-30);
+    Builder::Sub top;
+    if (n <= kLeafMax) {
+        // The root must be an inner node: one leaf child + one empty child whose box nothing can hit.
+        top.nodes.assign(16, 0.0f);
+        if (n > 0) Builder::put_box(top.nodes.data(), 0, root);
+        else { float* q = top.nodes.data(); q[0] = q[2] = q[8] = INFINITY; q[1] = q[3] = q[9] = -INFINITY; }
+        { float* q = top.nodes.data(); q[4] = q[6] = q[10] = INFINITY; q[5] = q[7] = q[11] = -INFINITY; }
+        Builder::put_child(top.nodes.data(), 0, Builder::leaf_ref(0, n));
+        Builder::put_child(top.nodes.data(), 1, Builder::leaf_ref(0, 0));
+        top.depth = 1;
+        top.cost = (double)n;
+    } else {
+        b.build_sub(0, n, 0, top);
+    }
+    res.nodes2.swap(top.nodes);
+    res.sah_cost = (float)top.cost;
+    collapse_to_bvh4(res, max_depth);
+    res.order = b.order;
+}
+}  // namespace
+
 void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult& res) {
     const auto t_start = std::chrono::steady_clock::now();
     const uint32_t n = (uint32_t)tris.size();
-    Builder b(tris, max_depth);
+    Builder b(max_depth);
     b.bounds.resize(n);
     for (int a = 0; a < 3; a++) b.centroid[a].resize(n);
     b.order.resize(n);
@@ -416,27 +440,7 @@ void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult&
         b.order[i] = i;
         root.add(bb);
     }
-    b.root_area = std::max((double)root.half_area(), 1e-30);
-    Builder::Sub top;
-    if (n <= kLeafMax) {
-        // The root must be an inner node: one leaf child + one empty child whose box nothing can hit.
-        top.nodes.assign(16, 0.0f);
-        Aabb none; for (int a = 0; a < 3; a++) { none.lo[a] = INFINITY; none.hi[a] = -INFINITY; }
-        if (n > 0) Builder::put_box(top.nodes.data(), 0, root);
-        else { float* q = top.nodes.data(); q[0] = q[2] = q[8] = INFINITY; q[1] = q[3] = q[9] = -INFINITY; }
-        { float* q = top.nodes.data(); q[4] = q[6] = q[10] = INFINITY; q[5] = q[7] = q[11] = -INFINITY; }
-        (void)none;
-        Builder::put_child(top.nodes.data(), 0, Builder::leaf_ref(0, n));
-        Builder::put_child(top.nodes.data(), 1, Builder::leaf_ref(0, 0));
-        top.depth = 1;
-        top.cost = (double)n;
-    } else {
-        b.build_sub(0, n, 0, top);
-    }
-    res.nodes2.swap(top.nodes);
-    res.sah_cost = (float)top.cost;
-    collapse_to_bvh4(res, max_depth);
-    res.order = b.order;
+    build_core(b, n, root, max_depth, res);
     res.tris.resize((size_t)n * 12);
     for (uint32_t i = 0; i < n; i++) {
         const BuildTri& t = tris[b.order[i]];
@@ -447,6 +451,29 @@ void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult&
         memcpy(q + 9, &t.gid, 4);
         q[10] = 0.0f; q[11] = 0.0f;
     }
+    res.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+}
+
+// The same builder over arbitrary boxes — the instance boxes of a top-level tree (tlas.rs:100-191): leaf references index
+// res.order (leaf position -> box index). The boxes are taken as they are (the caller pads them).
+void build_bvh_boxes(const std::vector<BuildBox>& boxes, uint32_t max_depth, BvhResult& res) {
+    const auto t_start = std::chrono::steady_clock::now();
+    const uint32_t n = (uint32_t)boxes.size();
+    Builder b(max_depth);
+    b.bounds.resize(n);
+    for (int a = 0; a < 3; a++) b.centroid[a].resize(n);
+    b.order.resize(n);
+    Aabb root; root.reset();
+    for (uint32_t i = 0; i < n; i++) {
+        Aabb bb;
+        for (int a = 0; a < 3; a++) { bb.lo[a] = boxes[i].lo[a]; bb.hi[a] = boxes[i].hi[a]; }
+        b.bounds[i] = bb;
+        for (int a = 0; a < 3; a++) b.centroid[a][i] = 0.5f * bb.lo[a] + 0.5f * bb.hi[a];
+        b.order[i] = i;
+        root.add(bb);
+    }
+    build_core(b, n, root, max_depth, res);
+    res.tris.clear();
     res.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
 }
 

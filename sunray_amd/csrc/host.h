@@ -78,6 +78,10 @@ void flatten_instances(const std::vector<HostMesh>& meshes, const FrameInstanceD
 // Binned-SAH binary tree with depth bounded by `max_depth`, leaves of <= kLeafMax (2) triangles, collapsed into a
 // 4-wide BVH (layout: traverse.h). max_stack = worst-case traversal stack entries for this tree.
 void build_bvh(const std::vector<BuildTri>& tris, uint32_t max_depth, BvhResult& out);
+// The same builder over arbitrary boxes (the instance boxes of a top-level tree): out.nodes + out.order (leaf references
+// index `order`: leaf position -> box index); out.tris stays empty.
+struct BuildBox { float lo[3], hi[3]; };
+void build_bvh_boxes(const std::vector<BuildBox>& boxes, uint32_t max_depth, BvhResult& out);
 
 // Rebuild-vs-update heuristic of one acceleration structure (acceleration_structure/mod.rs:62-148), on the POD
 // state the C ABI exposes (SrAsState). Ops: SR_OP_*.

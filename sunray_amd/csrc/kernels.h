@@ -39,10 +39,10 @@ struct PassArgs {
 }  // namespace srd
 
 int srk_launch_trace(const srd::DevScene& sc, const SrRay* rays, uint32_t n, SrHit* hits, uint32_t* occluded,
-                     uint32_t* queue_head, int any, int stats, int n_blocks, int stack_entries, hipStream_t stream);
+                     uint32_t* queue_head, int any, int stats, int two_level, int n_blocks, int stack_entries, hipStream_t stream);
 int srk_launch_shade(const srd::DevScene& sc, const SrHit* hits, uint32_t n, SrRayPayload* out, hipStream_t stream);
 int srk_launch_any_hit(const srd::DevScene& sc, const SrHit* hits, uint32_t n, uint32_t* ignored, hipStream_t stream);
-int srk_launch_pass(const srd::PassArgs& args, int which, int stats, int textured, int stack_entries, hipStream_t stream);
+int srk_launch_pass(const srd::PassArgs& args, int which, int stats, int textured, int two_level, int stack_entries, hipStream_t stream);
 // Tile schedule of the next launch from this launch's costs: per XCD band, tiles in descending cost (64 buckets).
 int srk_lds_rows(int stack_entries);
 uint32_t srk_pass_tile_count(uint32_t width, uint32_t rows);

@@ -32,7 +32,7 @@ SRD void flush_counter(unsigned long long* dst, uint32_t v) {
 // Ray-queue tracers. Persistent threads: the grid is sized to the machine (blocks_per_cu * 256 CUs),
 // each wave pulls 64 rays at a time from a global queue head until the queue is empty.
 // ---------------------------------------------------------------------------------------------
-template <bool ANY, bool STATS>
+template <bool ANY, bool STATS, bool TL>
 __global__ __launch_bounds__(kBlock) void trace_queue_kernel(DevScene sc, const SrRay* __restrict__ rays, uint32_t n,
                                                              SrHit* __restrict__ hits, uint32_t* __restrict__ occluded,
                                                              uint32_t* __restrict__ queue_head) {
@@ -52,7 +52,8 @@ __global__ __launch_bounds__(kBlock) void trace_queue_kernel(DevScene sc, const 
             const float4 ra = reinterpret_cast<const float4*>(rays)[ic * 2 + 0];
             const float4 rb = reinterpret_cast<const float4*>(rays)[ic * 2 + 1];
             TravHit h;
-            const bool found = traverse_ws<ANY, STATS>(sc, i < n, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), ra.w, rb.w, h, stack, kBlock, st);
+            const bool found = TL ? traverse_tl<ANY, STATS>(sc, i < n, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), ra.w, rb.w, h, stack, kBlock, st)
+                                  : traverse_ws<ANY, STATS>(sc, i < n, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), ra.w, rb.w, h, stack, kBlock, st);
             if (i < n) {
             n_queries++;
             if (ANY) occluded[i] = found ? 1u : 0u;
@@ -75,8 +76,10 @@ __global__ __launch_bounds__(kBlock) void shade_closest_hit_kernel(DevScene sc, 
     const SrHit h = hits[i];
     TravHit th;
     th.t = h.t; th.u = h.u; th.v = h.v; th.gid = (h.t < 0.0f || h.tri >= sc.n_tris) ? 0xFFFFFFFFu : h.tri;
-    th.slot = (th.gid != 0xFFFFFFFFu) ? sc.slot_of_gid[th.gid] : 0u;
-    const Payload p = shade_hit<true>(sc, th);
+    th.slot = 0u; th.inst = 0u;
+    const bool two_level = sc.tl_instances != nullptr;
+    if (th.gid != 0xFFFFFFFFu) { if (two_level) tl_locate(sc, th.gid, th.slot, th.inst); else th.slot = sc.slot_of_gid[th.gid]; }
+    const Payload p = two_level ? shade_hit<true, true>(sc, th) : shade_hit<true, false>(sc, th);
     SrRayPayload o;
     o.emission[0] = p.emission.x; o.emission[1] = p.emission.y; o.emission[2] = p.emission.z;
     o.dist = p.dist; o.albedo_packed = p.albedo_packed; o.normal_packed = p.normal_packed;
@@ -89,7 +92,9 @@ __global__ __launch_bounds__(kBlock) void any_hit_kernel(DevScene sc, const SrHi
     if (i >= n) return;
     const SrHit h = hits[i];
     const bool hit = !(h.t < 0.0f) && h.tri < sc.n_tris;
-    ignored[i] = (hit && any_hit_ignores(sc, sc.slot_of_gid[h.tri], h.u, h.v)) ? 1u : 0u;
+    uint32_t slot = 0u, inst = 0u;
+    if (hit) { if (sc.tl_instances) tl_locate(sc, h.tri, slot, inst); else slot = sc.slot_of_gid[h.tri]; }
+    ignored[i] = (hit && any_hit_ignores(sc, slot, h.u, h.v)) ? 1u : 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -119,12 +124,18 @@ struct PixelCtx {
     uint32_t n_reused = 0;   // closest-hit queries of the reference answered from the primary-hit hand-off instead of a traversal
 };
 
+// TraceRay of the passes: V bit 2 selects the two-level walk (traverse_tl) over the one-level one with work stealing (traverse_ws)
+template <int V, bool ANY>
+SRD bool trace_ray(PixelCtx& cx, bool want, f3 o, f3 d, float tmin, float tmax, TravHit& h) {
+    if constexpr ((V & 4) != 0) return traverse_tl<ANY, (V & 1) != 0>(cx.a.sc, want, o, d, tmin, tmax, h, cx.stack, kPassBlock, cx.st);
+    else return traverse_ws<ANY, (V & 1) != 0>(cx.a.sc, want, o, d, tmin, tmax, h, cx.stack, kPassBlock, cx.st);
+}
 template <int V>
 SRD Payload trace_closest_shaded(PixelCtx& cx, f3 o, f3 d, float tmin, float tmax) {
     TravHit h;
-    traverse_ws<false, (V & 1) != 0>(cx.a.sc, true, o, d, tmin, tmax, h, cx.stack, kPassBlock, cx.st);
+    trace_ray<V, false>(cx, true, o, d, tmin, tmax, h);
     cx.n_closest++;
-    return shade_hit<(V & 2) != 0>(cx.a.sc, h);
+    return shade_hit<(V & 2) != 0, (V & 4) != 0>(cx.a.sc, h);
 }
 // The shadow-ray idiom of every visibility query: prd.dist preset to 1.0, the miss shader writes -1;
 // segments <= 0.002 are not traced and count as visible. Returns the resulting prd.dist.
@@ -133,7 +144,7 @@ SRD float trace_shadow(PixelCtx& cx, f3 o, f3 d, float dist) {
     if (dist > 0.002f) {
         TravHit h;
         cx.n_any++;
-        return traverse_ws<true, (V & 1) != 0>(cx.a.sc, true, o, d, 0.001f, dist - 0.001f, h, cx.stack, kPassBlock, cx.st) ? 1.0f : -1.0f;
+        return trace_ray<V, true>(cx, true, o, d, 0.001f, dist - 0.001f, h) ? 1.0f : -1.0f;
     }
     return -1.0f;
 }
@@ -357,7 +368,7 @@ __global__ void tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* _
 template <int V, bool ANY>
 SRD bool ws_query(PixelCtx& cx, bool want, f3 o, f3 d, float tmin, float tmax, TravHit& h) {
     if (want) { if (ANY) cx.n_any++; else cx.n_closest++; }
-    return traverse_ws<ANY, (V & 1) != 0>(cx.a.sc, want, o, d, tmin, tmax, h, cx.stack, kPassBlock, cx.st);
+    return trace_ray<V, ANY>(cx, want, o, d, tmin, tmax, h);
 }
 
 template <int V>
@@ -656,7 +667,7 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
         float roughness = 0.5f, metallic = 0.0f;
         if (in_loop) {
             if (reuse_primary) { prd = load_payload(a.primary_payload + pix); cx.n_reused++; }
-            else prd = shade_hit<(V & 2) != 0>(sc, h);
+            else prd = shade_hit<(V & 2) != 0, (V & 4) != 0>(sc, h);
             if (prd.dist < 0.0f) in_loop = false;                                      // :82-84
             else {
                 hit_normal = unpack_normal(prd.normal_packed);
@@ -961,18 +972,22 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
 using namespace srd;
 
 int srk_launch_trace(const DevScene& sc, const SrRay* rays, uint32_t n, SrHit* hits, uint32_t* occluded,
-                     uint32_t* queue_head, int any, int stats, int n_blocks, int stack_entries, hipStream_t stream) {
+                     uint32_t* queue_head, int any, int stats, int two_level, int n_blocks, int stack_entries, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(queue_head, 0, 16, stream);
     if (e != hipSuccess) return (int)e;
     if (n == 0) return 0;
     dim3 grid(n_blocks), block(kBlock);
     const size_t lds = (size_t)(stack_entries + kLdsExtraRows) * kBlock * sizeof(int);
-    if (any) {
-        if (stats) trace_queue_kernel<true, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head);
-        else trace_queue_kernel<true, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head);
-    } else {
-        if (stats) trace_queue_kernel<false, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head);
-        else trace_queue_kernel<false, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head);
+    const int v = (any ? 1 : 0) | (stats ? 2 : 0) | (two_level ? 4 : 0);
+    switch (v) {
+        case 0: trace_queue_kernel<false, false, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
+        case 1: trace_queue_kernel<true, false, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
+        case 2: trace_queue_kernel<false, true, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
+        case 3: trace_queue_kernel<true, true, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
+        case 4: trace_queue_kernel<false, false, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
+        case 5: trace_queue_kernel<true, false, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
+        case 6: trace_queue_kernel<false, true, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
+        default: trace_queue_kernel<true, true, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
     }
     return (int)hipGetLastError();
 }
@@ -990,8 +1005,8 @@ int srk_launch_any_hit(const DevScene& sc, const SrHit* hits, uint32_t n, uint32
 }
 
 // Kernel variant V: bit 0 = traversal statistics (instrumented build), bit 1 = the scene has textured materials
-// (closest_hit's texture half compiled in). Untextured scenes run the variant without it.
-int srk_launch_pass(const PassArgs& args_in, int which, int stats, int textured, int stack_entries, hipStream_t stream) {
+// (closest_hit's texture half compiled in; untextured scenes run the variant without it), bit 2 = two-level structure.
+int srk_launch_pass(const PassArgs& args_in, int which, int stats, int textured, int two_level, int stack_entries, hipStream_t stream) {
     PassArgs args = args_in;
     args.tiles_x = (args.x1 - args.x0 + kPassTile - 1) / kPassTile;
     args.tiles_y = (args.y1 - args.y0 + kPassTile - 1) / kPassTile;
@@ -1000,20 +1015,28 @@ int srk_launch_pass(const PassArgs& args_in, int which, int stats, int textured,
     if (n_tiles == 0) return 0;
     dim3 grid(args.order_cap * 8), block(kPassBlock);
     const size_t lds = (size_t)(stack_entries + kLdsExtraRows) * kPassBlock * sizeof(int);
-    const int v = (stats ? 1 : 0) | (textured ? 2 : 0);
+    const int v = (stats ? 1 : 0) | (textured ? 2 : 0) | (two_level ? 4 : 0);
     if (which == 0) {
         switch (v) {
             case 0: ris_kernel<0><<<grid, block, lds, stream>>>(args); break;
             case 1: ris_kernel<1><<<grid, block, lds, stream>>>(args); break;
             case 2: ris_kernel<2><<<grid, block, lds, stream>>>(args); break;
-            default: ris_kernel<3><<<grid, block, lds, stream>>>(args); break;
+            case 3: ris_kernel<3><<<grid, block, lds, stream>>>(args); break;
+            case 4: ris_kernel<4><<<grid, block, lds, stream>>>(args); break;
+            case 5: ris_kernel<5><<<grid, block, lds, stream>>>(args); break;
+            case 6: ris_kernel<6><<<grid, block, lds, stream>>>(args); break;
+            default: ris_kernel<7><<<grid, block, lds, stream>>>(args); break;
         }
     } else {
         switch (v) {
             case 0: final_kernel<0><<<grid, block, lds, stream>>>(args); break;
             case 1: final_kernel<1><<<grid, block, lds, stream>>>(args); break;
             case 2: final_kernel<2><<<grid, block, lds, stream>>>(args); break;
-            default: final_kernel<3><<<grid, block, lds, stream>>>(args); break;
+            case 3: final_kernel<3><<<grid, block, lds, stream>>>(args); break;
+            case 4: final_kernel<4><<<grid, block, lds, stream>>>(args); break;
+            case 5: final_kernel<5><<<grid, block, lds, stream>>>(args); break;
+            case 6: final_kernel<6><<<grid, block, lds, stream>>>(args); break;
+            default: final_kernel<7><<<grid, block, lds, stream>>>(args); break;
         }
     }
     return (int)hipGetLastError();

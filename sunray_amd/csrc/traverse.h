@@ -82,7 +82,12 @@ struct DevScene {
     const DevTexture* textures;    // [n_images]
     const DevInstance* instances;
     const DevLight* lights;        // [num_lights]
-    const uint32_t* slot_of_gid;   // global triangle index -> leaf-order slot (sr_shade_closest_hit only)
+    const uint32_t* slot_of_gid;   // global triangle index -> leaf-order slot (sr_shade_closest_hit only); two-level: per-mesh primitive -> slot tables
+    // two-level structure (DevTlInstance below; null / 0 in the flattened form): `nodes` is then the top-level tree over instance
+    // boxes, `tris` / `shade` / `shade_tex` hold every mesh's records once, in OBJECT space and leaf order
+    const float4* blas_nodes;      // the meshes' trees, one after the other (child references already offset)
+    const uint32_t* tl_inst;       // leaf position of the top-level tree -> instance index
+    const struct DevTlInstance* tl_instances;
     unsigned long long* counters;  // [0]=closest queries [1]=any queries [2]=boxes [3]=tris [4]=primary hits reused
     uint32_t num_lights;
     uint32_t n_tris;
@@ -93,6 +98,22 @@ struct DevScene {
 struct TravHit {
     float t, u, v;
     uint32_t gid, slot;  // gid == 0xFFFFFFFF: miss; slot = position in tris/shade
+    uint32_t inst;       // instance index (set by the two-level walk; the flattened form reads it from the shade record)
+};
+
+// One instance of the two-level structure — the counterpart of a VkAccelerationStructureInstanceKHR (resource_manager.rs:236-251:
+// transform, custom index, mask 0xFF, cull disabled, BLAS reference) plus what the walk needs to stay conservative.
+struct DevTlInstance {   // 128 B
+    float w2o[12];        // row-major 3x4 inverse of o2w (computed in double): the object-space ray = w2o * world ray; steers box
+                          // culling only — triangles are tested in WORLD space, so a hit has the bits of the flattened form
+    float o2w[12];        // the instance transform: vertices go to world space with transform_point's operation order
+    uint32_t blas_root;   // root node of the mesh's tree in blas_nodes
+    uint32_t tri_offset;  // global triangle index of the instance's primitive 0 (instance-major order)
+    float pad_a, pad_b;   // the mesh's boxes are widened by pad_a * |ray origin|_inf + pad_b (object units): bounds the rounding of
+                          // the ray transform and of the world-space vertices against the object-space boxes
+    uint32_t mesh_slot;
+    uint32_t prim_base;   // of the mesh's primitive -> slot table in slot_of_gid
+    uint32_t _pad[2];
 };
 
 struct TravStats { uint32_t boxes, tris; };
@@ -330,7 +351,7 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     const unsigned long long k = keys[tid];
-    hit.t = -1.0f; hit.u = 0.0f; hit.v = 0.0f; hit.gid = 0xFFFFFFFFu; hit.slot = 0u;
+    hit.t = -1.0f; hit.u = 0.0f; hit.v = 0.0f; hit.gid = 0xFFFFFFFFu; hit.slot = 0u; hit.inst = 0u;
     if (ANY) return k == 0ull;
     if (k != ~0ull) {
         hit.gid = (uint32_t)k;
@@ -338,6 +359,147 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
         hit.v = __int_as_float(pay[2 * stride + tid]); hit.slot = (uint32_t)pay[3 * stride + tid];
     }
     return k != ~0ull;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two-level walk (optional form of the structure for instance-heavy scenes; the reference's TLAS over BLASes, tlas.rs:155-191,
+// resource_manager.rs:236-251). The top-level tree holds padded world-space boxes of the instances; entering an instance
+// transforms the ray into the mesh's object space for the BOX tests only (the parameter t is the same in both spaces, the
+// direction is not re-normalised). A leaf's triangles are brought to world space on the fly — the same transform_point
+// operations that flatten them in the one-level form — and tested against the world-space ray, so a hit carries exactly the
+// bits of the flattened form; the tie rule (smallest t, then lowest global triangle index = instance-major) is unchanged.
+// Culling stays conservative through the per-instance padding (DevTlInstance::pad_*). One lane = one ray, no work stealing:
+// a stolen subtree would need its instance. Stack: top-level entries below, a kLeave marker, then the mesh's entries.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLeave = 0x7ffffffe;
+struct NodePlanesTl {
+    uint32_t nx, ny, nz, fx, fy, fz;
+    float ax, ay, az;
+    float bnx, bny, bnz, bfx, bfy, bfz;   // near / far offsets: (origin - o) * inv -/+ pad * |inv|
+};
+template <int C>
+SRD bool child_hit_tl(const NodePlanesTl& p, float t_lo, float t_hi, float& tnear) {
+    const float t0 = fmaxf(fmaxf(fmaf(plane_q<C>(p.nx), p.ax, p.bnx), fmaf(plane_q<C>(p.ny), p.ay, p.bny)),
+                           fmaxf(fmaf(plane_q<C>(p.nz), p.az, p.bnz), t_lo));
+    float far = fminf(fminf(fmaf(plane_q<C>(p.fx), p.ax, p.bfx), fmaf(plane_q<C>(p.fy), p.ay, p.bfy)), fmaf(plane_q<C>(p.fz), p.az, p.bfz));
+    far = fmaf(fabsf(far), 5e-7f, far);
+    tnear = t0;
+    return t0 <= fminf(far, t_hi);
+}
+#define SR_TL_POP() (sp == 0 ? kSentinel : stack_base[(--sp) * stride])
+template <bool ANY, bool STATS>
+SRD bool traverse_tl(const DevScene& sc, bool want, f3 o, f3 d, float tmin, float tmax, TravHit& hit, int* lds_col, int stride, TravStats& st) {
+    const float4* __restrict__ tris = sc.tris;
+    int* const stack_base = lds_col + kWsRows * stride;
+    const float t_lo = fminf(tmin, 0.0f) - fabsf(tmin);
+    float cull = fmaf(fabsf(tmax), 1e-5f, tmax);
+    float best_t = tmax, best_u = 0.0f, best_v = 0.0f;
+    uint32_t best_gid = 0xFFFFFFFFu, best_slot = 0u, best_inst = 0u;
+    const float o_mag = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+    int sp = 0;
+    int node = want ? 0 : kSentinel;
+    bool in_blas = false, found = false;
+    uint32_t inst = 0u;
+    f3 ro = o;                                // ray of the space being walked (direction enters through inv only)
+    RaySetup rs = ray_setup(o, d);
+    f3 pad = splat(0.0f);                     // padding of the current instance times |1/d| per axis
+    while (node != kSentinel) {
+        if (node == kLeave) {                 // the instance is done: back to the world-space ray
+            in_blas = false; ro = o; rs = ray_setup(o, d); pad = splat(0.0f);
+            node = SR_TL_POP();
+        } else if (node >= 0) {
+            const float4* n = (in_blas ? sc.blas_nodes : sc.nodes) + (size_t)node * 4;
+            const float4 h0 = n[0], q1 = n[1], q2 = n[2], qc = n[3];
+            const int4 child = make_int4(__float_as_int(qc.x), __float_as_int(qc.y), __float_as_int(qc.z), __float_as_int(qc.w));
+            if (STATS) st.boxes += 4;
+            const uint32_t ex = __float_as_uint(h0.w);
+            const uint32_t LX = __float_as_uint(q1.x), LY = __float_as_uint(q1.y), LZ = __float_as_uint(q1.z);
+            const uint32_t HX = __float_as_uint(q1.w), HY = __float_as_uint(q2.x), HZ = __float_as_uint(q2.y);
+            NodePlanesTl p;
+            const bool sgx = __float_as_int(rs.inv.x) < 0, sgy = __float_as_int(rs.inv.y) < 0, sgz = __float_as_int(rs.inv.z) < 0;
+            p.nx = sgx ? HX : LX; p.fx = sgx ? LX : HX;
+            p.ny = sgy ? HY : LY; p.fy = sgy ? LY : HY;
+            p.nz = sgz ? HZ : LZ; p.fz = sgz ? LZ : HZ;
+            p.ax = __uint_as_float((ex & 0xFFu) << 23) * rs.inv.x; p.ay = __uint_as_float(((ex >> 8) & 0xFFu) << 23) * rs.inv.y;
+            p.az = __uint_as_float(((ex >> 16) & 0xFFu) << 23) * rs.inv.z;
+            const float bx = (h0.x - ro.x) * rs.inv.x, by = (h0.y - ro.y) * rs.inv.y, bz = (h0.z - ro.z) * rs.inv.z;
+            p.bnx = bx - pad.x; p.bfx = bx + pad.x; p.bny = by - pad.y; p.bfy = by + pad.y; p.bnz = bz - pad.z; p.bfz = bz + pad.z;
+            float n0, n1, n2, n3;
+            const bool b0 = child_hit_tl<0>(p, t_lo, cull, n0);
+            const bool b1 = child_hit_tl<1>(p, t_lo, cull, n1);
+            const bool b2 = child_hit_tl<2>(p, t_lo, cull, n2);
+            const bool b3 = child_hit_tl<3>(p, t_lo, cull, n3);
+            uint32_t k0, k1, k2, k3;      // nearest child first (existence queries too: no stealing here, so nothing to leave behind)
+            k0 = b0 ? ((__float_as_uint(fmaxf(n0, 0.0f)) & ~3u) | 0u) : 0xFFFFFFFFu;
+            k1 = b1 ? ((__float_as_uint(fmaxf(n1, 0.0f)) & ~3u) | 1u) : 0xFFFFFFFFu;
+            k2 = b2 ? ((__float_as_uint(fmaxf(n2, 0.0f)) & ~3u) | 2u) : 0xFFFFFFFFu;
+            k3 = b3 ? ((__float_as_uint(fmaxf(n3, 0.0f)) & ~3u) | 3u) : 0xFFFFFFFFu;
+            const uint32_t kmin = min(min(k0, k1), min(k2, k3));
+            stack_base[sp * stride] = child.x; sp += (b0 && k0 != kmin) ? 1 : 0;
+            stack_base[sp * stride] = child.y; sp += (b1 && k1 != kmin) ? 1 : 0;
+            stack_base[sp * stride] = child.z; sp += (b2 && k2 != kmin) ? 1 : 0;
+            stack_base[sp * stride] = child.w; sp += (b3 && k3 != kmin) ? 1 : 0;
+            node = (kmin != 0xFFFFFFFFu) ? pick(child, kmin & 3u) : SR_TL_POP();
+        } else {
+            const uint32_t lv = ~(uint32_t)node;
+            const uint32_t first = lv >> 3, cnt = lv & 7u;
+            if (!in_blas) {
+                // top-level leaf: enter its first instance, the others wait on the stack as leaves of one
+                if (cnt == 0u) { node = SR_TL_POP(); continue; }
+                for (uint32_t k = 1; k < cnt; k++) { stack_base[sp * stride] = (int)~(((first + k) << 3) | 1u); sp++; }
+                inst = sc.tl_inst[first];
+                const float4* q = reinterpret_cast<const float4*>(sc.tl_instances + inst);
+                const float4 r0 = q[0], r1 = q[1], r2 = q[2], m6 = q[6];
+                ro = mk3(((r0.x * o.x + r0.y * o.y) + r0.z * o.z) + r0.w, ((r1.x * o.x + r1.y * o.y) + r1.z * o.z) + r1.w,
+                         ((r2.x * o.x + r2.y * o.y) + r2.z * o.z) + r2.w);
+                const f3 rd = mk3((r0.x * d.x + r0.y * d.y) + r0.z * d.z, (r1.x * d.x + r1.y * d.y) + r1.z * d.z, (r2.x * d.x + r2.y * d.y) + r2.z * d.z);
+                rs = ray_setup(ro, rd);
+                const float pd = fmaf(m6.z, o_mag, m6.w);
+                pad = mk3(pd * fabsf(rs.inv.x), pd * fabsf(rs.inv.y), pd * fabsf(rs.inv.z));
+                stack_base[sp * stride] = kLeave; sp++;
+                in_blas = true;
+                node = (int)__float_as_uint(m6.x);
+            } else {
+                const float4* q = reinterpret_cast<const float4*>(sc.tl_instances + inst);
+                const float4 m0 = q[3], m1 = q[4], m2 = q[5], m6 = q[6];
+                const uint32_t tri_offset = __float_as_uint(m6.y);
+                for (uint32_t k = 0; k < cnt && !found; k++) {
+                    const uint32_t slot = first + k;
+                    const float4 t0 = tris[(size_t)slot * 3 + 0], t1 = tris[(size_t)slot * 3 + 1], t2 = tris[(size_t)slot * 3 + 2];
+                    if (STATS) st.tris += 1;
+                    // transform_point (rt_utils.slang:278-281), exactly as the one-level form flattens a triangle
+                    const f3 a = mk3(t0.x, t0.y, t0.z), b = mk3(t0.w, t1.x, t1.y), c = mk3(t1.z, t1.w, t2.x);
+                    const f3 wa = mk3(((m0.x * a.x + m0.y * a.y) + m0.z * a.z) + m0.w * 1.0f, ((m1.x * a.x + m1.y * a.y) + m1.z * a.z) + m1.w * 1.0f,
+                                      ((m2.x * a.x + m2.y * a.y) + m2.z * a.z) + m2.w * 1.0f);
+                    const f3 wb = mk3(((m0.x * b.x + m0.y * b.y) + m0.z * b.z) + m0.w * 1.0f, ((m1.x * b.x + m1.y * b.y) + m1.z * b.z) + m1.w * 1.0f,
+                                      ((m2.x * b.x + m2.y * b.y) + m2.z * b.z) + m2.w * 1.0f);
+                    const f3 wc = mk3(((m0.x * c.x + m0.y * c.y) + m0.z * c.z) + m0.w * 1.0f, ((m1.x * c.x + m1.y * c.y) + m1.z * c.z) + m1.w * 1.0f,
+                                      ((m2.x * c.x + m2.y * c.y) + m2.z * c.z) + m2.w * 1.0f);
+                    float t, u, v;
+                    if (intersect_tri(o, d, wa, wb - wa, wc - wa, tmin, tmax, t, u, v)) {
+                        if (ANY) { found = true; break; }
+                        const uint32_t gid = tri_offset + __float_as_uint(t2.y);
+                        if (t < best_t || (t == best_t && gid < best_gid)) {
+                            best_t = t; best_u = u; best_v = v; best_gid = gid; best_slot = slot; best_inst = inst;
+                            cull = fminf(cull, fmaf(fabsf(t), 1e-5f, t));
+                        }
+                    }
+                }
+                node = (ANY && found) ? kSentinel : SR_TL_POP();
+            }
+        }
+    }
+    hit.t = -1.0f; hit.u = 0.0f; hit.v = 0.0f; hit.gid = 0xFFFFFFFFu; hit.slot = 0u; hit.inst = 0u;
+    if (ANY) return found;
+    if (best_gid != 0xFFFFFFFFu) { hit.t = best_t; hit.u = best_u; hit.v = best_v; hit.gid = best_gid; hit.slot = best_slot; hit.inst = best_inst; }
+    return best_gid != 0xFFFFFFFFu;
+}
+// Two-level form: leaf slot and instance of a global triangle index (test hooks only: sr_shade_closest_hit, sr_any_hit_ignores).
+SRD void tl_locate(const DevScene& sc, uint32_t gid, uint32_t& slot, uint32_t& inst) {
+    uint32_t lo = 0u, hi = sc.n_instances;
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (sc.tl_instances[mid].tri_offset <= gid) lo = mid; else hi = mid; }
+    inst = lo;
+    slot = sc.slot_of_gid[sc.tl_instances[lo].prim_base + (gid - sc.tl_instances[lo].tri_offset)];
 }
 
 // Payload of one closest-hit query in registers (rt_types.slang:9-16).
@@ -463,7 +625,7 @@ SRD bool any_hit_ignores(const DevScene& sc, uint32_t slot, float u, float v) {
     return base_color.w < mt.alpha_cutoff;                                               // :40-42
 }
 
-template <bool TEX>
+template <bool TEX, bool TL = false>
 SRD Payload shade_hit(const DevScene& sc, const TravHit& h) {
     Payload pl;
     pl.emission = splat(0.0f);
@@ -472,7 +634,7 @@ SRD Payload shade_hit(const DevScene& sc, const TravHit& h) {
     const float4 s0 = sc.shade[(size_t)h.slot * 3 + 0];
     const float4 s1 = sc.shade[(size_t)h.slot * 3 + 1];
     const float4 s2 = sc.shade[(size_t)h.slot * 3 + 2];
-    const uint32_t inst = __float_as_uint(s2.y), mesh = __float_as_uint(s2.z);
+    const uint32_t inst = TL ? h.inst : __float_as_uint(s2.y), mesh = __float_as_uint(s2.z);   // two-level: the record belongs to the mesh, not to an instance
     const f3 bary = mk3(1.0f - h.u - h.v, h.u, h.v);
     const f3 na = mk3(s0.x, s0.y, s0.z), nb = mk3(s0.w, s1.x, s1.y), nc = mk3(s1.z, s1.w, s2.x);
     const f3 normal = na * bary.x + nb * bary.y + nc * bary.z;

@@ -161,10 +161,12 @@ class DeviceFrame:
 class Scene:
     """ResourceManager + acceleration structures of one GPU (sr_scene_*)."""
 
-    def __init__(self, device_index=0):
+    def __init__(self, device_index=0, instancing=None):
         self._h = C.c_void_p()
         check(lib().sr_scene_create(C.c_int(device_index), C.byref(self._h)))
         self.device_index = device_index
+        if instancing is not None:
+            self.set_instancing(instancing)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -238,6 +240,17 @@ class Scene:
         check(lib().sr_scene_read_tile_costs(self._h, C.c_int(which), C.c_uint32(width), C.c_uint32(y0), C.c_uint32(rows), _p(out),
                                              C.c_uint32(len(out)), C.byref(n)))
         return out[:n.value]
+
+    def set_instancing(self, mode):
+        """Form of the acceleration structure at the next set_instances: "auto" | "flat" | "two_level" (sr_scene_set_instancing)."""
+        check(lib().sr_scene_set_instancing(self._h, C.c_uint32({"auto": 0, "flat": 1, "two_level": 2}[mode])))
+        return self
+
+    def two_level(self):
+        """True while the structure is built in the two-level form."""
+        now = C.c_uint32()
+        check(lib().sr_scene_instancing(self._h, None, C.byref(now)))
+        return bool(now.value)
 
     def force_next_op(self, op):
         check(lib().sr_scene_force_next_op(self._h, C.c_uint32(op)))

@@ -374,3 +374,51 @@ def atrium(columns_per_side=20, col_segments=96, col_rings=30, floor_div=64, tex
         add(lv, li, abi.material(base_color=(0.8, 0.8, 0.8, 1), roughness=0.5, emissive_factor=tuple(hue), emissive_strength=9.0 + (k % 5), textures=textures),
             [abi.IDENTITY_TRANSFORM.copy()])
     return s
+
+
+# ---- instanced field: many instances of few meshes (two-level instancing) ---------------
+def instanced_field(n_instances=300, segments=24, rings=12, n_meshes=3, seed=5, extent=12.0, nonuniform=True, n_lamps=4):
+    """`n_instances` rotated, (non-uniformly) scaled and translated instances of `n_meshes` bumpy blobs (2 * segments * (rings - 1)
+    triangles each: 24 x 12 -> 528) over a ground quad, lit by a few emissive quads. Transforms are general affine maps
+    (rotation about an arbitrary axis, per-axis scales within a factor of three, a small shear), which is what separates an
+    object-space walk from a world-space one."""
+    rng = np.random.default_rng(seed)
+    s = SceneDesc("instanced_field_%d" % n_instances, camera_pos=(0.0, 9.0, 1.6 * extent), camera_target=(0.0, 0.8, 0.0), fov_y=50.0)
+    key = 1
+    blob_keys = []
+    for m in range(n_meshes):
+        v, idx = uv_sphere(1.0, segments, rings)
+        p = v["position"].astype(np.float64)
+        bump = 1.0 + 0.25 * np.sin(3.0 * p[:, 0] + m) * np.cos(2.0 * p[:, 1] - m) + 0.15 * np.sin(5.0 * p[:, 2])
+        v["position"] = (p * bump[:, None]).astype(np.float32)
+        mat = abi.material(base_color=(0.3 + 0.2 * m, 0.7 - 0.15 * m, 0.4, 1.0), metallic=0.0 if m else 0.95, roughness=0.6 if m else 0.05)
+        s.meshes.append(MeshDesc(key, v, idx, mat))
+        blob_keys.append(key)
+        key += 1
+    gv, gi = quad((-2 * extent, 0, -2 * extent), (-2 * extent, 0, 2 * extent), (2 * extent, 0, 2 * extent), (2 * extent, 0, -2 * extent), (0, 1, 0))
+    s.meshes.append(MeshDesc(key, gv, gi, abi.material(base_color=(0.7, 0.7, 0.7, 1.0), roughness=0.8)))
+    ground_key = key
+    key += 1
+    lv, li = quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), (0, -1, 0))
+    s.meshes.append(MeshDesc(key, lv, li, abi.material(base_color=(1, 1, 1, 1), emissive_factor=(1.0, 0.95, 0.85), emissive_strength=18.0)))
+    lamp_key = key
+    per_key = {k: [] for k in blob_keys}
+    for i in range(n_instances):
+        axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+        ang = rng.uniform(0, 2 * np.pi)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+        sc = rng.uniform(0.25, 0.75, size=3) if nonuniform else np.full(3, rng.uniform(0.3, 0.7))
+        S = np.diag(sc)
+        if nonuniform:
+            S[0, 1] = 0.15 * sc[0]
+        M = R @ S
+        t = np.array([rng.uniform(-extent, extent), rng.uniform(0.3, 3.5), rng.uniform(-extent, extent)])
+        xf = np.concatenate([M, t[:, None]], axis=1).astype(np.float32).reshape(12)
+        per_key[blob_keys[i % n_meshes]].append(xf)
+    for k in blob_keys:
+        if per_key[k]:
+            s.instances.append((k, per_key[k]))
+    s.instances.append((ground_key, [translate(0, 0, 0)]))
+    s.instances.append((lamp_key, [translate(extent * (0.6 * np.cos(2.4 * j)), 7.0 + 0.5 * j, extent * (0.6 * np.sin(2.4 * j)), 1.5) for j in range(n_lamps)]))
+    return s
