@@ -509,7 +509,13 @@ def test_error_behaviour(rt, blue_noise):
     counts[0] = 0xFFFFFFFF                     # 2^32 - 1 instances of a 2-triangle mesh: the 32-bit triangle offset would wrap
     with pytest.raises(SunrayError) as e:
         check(lib().sr_scene_set_instances(g._h, keys, counts, C.c_uint32(1), C.c_void_p(8)))
+    assert e.value.code == -5 and "2^32 - 1 triangles" in e.value.description
+    g.set_instancing("flat")                   # the one-level form stops at 2^28 triangles (leaf reference encoding); the two-level form takes over in auto mode
+    counts[0] = 1 << 27
+    with pytest.raises(SunrayError) as e:
+        check(lib().sr_scene_set_instances(g._h, keys, counts, C.c_uint32(1), C.c_void_p(8)))
     assert e.value.code == -5 and "2^28 triangles" in e.value.description
+    g.set_instancing("auto")
     g.set_instances([(1, [abi.IDENTITY_TRANSFORM])])          # the scene is still usable
     rays = rt.rays_to_device(random_rays(64, 1))
     with pytest.raises(SunrayError) as e:
