@@ -638,14 +638,8 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
     uint32_t rng = init_rng(px, py, a.frame_count, W);                                 // :37
     const int BOUNCES = (int)a.cfg.max_bounces;
     const int SHADOW_BOUNCES = (int)a.cfg.shadow_bounces;
-    float bn_1 = 0.0f, bn_2 = 0.0f;
-    if (active) {                                                                      // :44-50
-        const int bw = (int)a.blue_noise_w, bh = (int)a.blue_noise_h;
-        const int n1x = ipx % bw, n1y = ipy % bh;
-        const int n2x = (ipx + 47) % bw, n2y = (ipy + 71) % bh;
-        bn_1 = (float)a.blue_noise_tex[((size_t)n1y * bw + n1x) * 4] / 255.0f;
-        bn_2 = (float)a.blue_noise_tex[((size_t)n2y * bw + n2x) * 4] / 255.0f;
-    }
+    // :44-50 the two blue-noise texels of the pixel are fetched where they are used (the BRDF bounce of bounce 0, :393-396): with
+    // ReSTIR on, most walks end at their first rough hit and never get there
     f3 origin, rayDir0; f2 inUV;
     primary_ray(a.mats, px, py, W, H, origin, rayDir0, inUV);                          // :58-67
     f3 rayOrigin = origin, rayDir = rayDir0;
@@ -910,6 +904,11 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
             const float p_specular = clampf(maxc(F), 0.05f, 1.0f);
             float r1, r2;
             if (bounce == 0) {
+                const int bw = (int)a.blue_noise_w, bh = (int)a.blue_noise_h;      // :44-50
+                const int n1x = ipx % bw, n1y = ipy % bh;
+                const int n2x = (ipx + 47) % bw, n2y = (ipy + 71) % bh;
+                const float bn_1 = (float)a.blue_noise_tex[((size_t)n1y * bw + n1x) * 4] / 255.0f;
+                const float bn_2 = (float)a.blue_noise_tex[((size_t)n2y * bw + n2x) * 4] / 255.0f;
                 r1 = fracf(bn_1 + (float)(a.frame_count % 1024u) * 0.75487766f);
                 r2 = fracf(bn_2 + (float)(a.frame_count % 1024u) * 0.56984029f);
             } else {
