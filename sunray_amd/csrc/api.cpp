@@ -560,12 +560,16 @@ int full_build(SrScene* s);
 // update cost O(instances x triangles). This form keeps one tree per MESH in object space and a top-level tree over padded
 // instance boxes: a changed instance list costs a top-level rebuild (host, O(instances log instances)) and one 128-byte record
 // per instance, whatever the meshes hold. Hits are those of the one-level form bit for bit (traverse.h: traverse_tl).
-constexpr uint32_t kTlStackCap = 60;     // LDS stack entries a two-level walk may need (top-level + marker + mesh tree)
+constexpr uint32_t kTlStackCap = 47;     // LDS stack entries a two-level walk may need (top-level + pending instances of a leaf + marker + mesh
+                                         // tree): with the spare level and the 8 work rows, 56 rows = 56 KB for the 256-thread queue tracers
 
-uint32_t depth_for(uint64_t n_items) {   // binary depth that lets the builder reach leaves of <= 2 items with slack for SAH splits
+uint32_t min_depth_for(uint64_t n_items) {   // binary depth a median split needs to reach leaves of <= 2 items
     uint32_t need = 2;
     for (uint64_t c = (n_items + 1) / 2; c > 1; c = (c + 1) / 2) need++;
-    return std::max(6u, std::min((uint32_t)srd::kMaxBinaryDepth, need + 6u));
+    return need;
+}
+uint32_t depth_for(uint64_t n_items) {       // ... with slack for SAH splits (the collapse widens nodes until the budget is used)
+    return std::max(6u, std::min((uint32_t)srd::kMaxBinaryDepth, min_depth_for(n_items) + 6u));
 }
 
 // Object-space tree of one mesh (OpType::SlowBuild of a BLAS, blas.rs:178): same builder, same triangle padding.
@@ -587,7 +591,7 @@ int build_blas(SrScene* s, uint32_t slot) {
         t.prim = p; t.inst = 0; t.gid = p;
     }
     srh::BvhResult bvh;
-    srh::build_bvh(tris, depth_for(n), bvh);
+    srh::build_bvh(tris, std::min(depth_for(n), 26u), bvh);          // leaves the top-level tree at least 18 of the kTlStackCap entries
     b.nodes.swap(bvh.nodes);
     b.n_tris = n; b.n_nodes = bvh.n_nodes; b.max_stack = bvh.max_stack; b.max_depth = bvh.max_depth; b.build_ms = bvh.build_ms;
     b.max_edge_sum = max_edge; b.max_abs_vertex = max_abs;
@@ -744,8 +748,11 @@ int two_level_build(SrScene* s) {
         boxes.push_back(bx);
         box_inst.push_back((uint32_t)i);
     }
+    // the stack budget of the top-level tree is what the deepest mesh tree leaves of the walk's LDS stack
+    const uint32_t left = kTlStackCap > s->blas_stack + srl::kLeafMax + 1u ? kTlStackCap - s->blas_stack - srl::kLeafMax - 1u : 0u;
+    if (left < min_depth_for(boxes.size())) return fail(SR_ERR_UNSUPPORTED, "two-level structure: instance count and mesh size together need a deeper traversal stack than the kernels provide");
     srh::BvhResult tl;
-    srh::build_bvh_boxes(boxes, depth_for(boxes.size()), tl);
+    srh::build_bvh_boxes(boxes, std::min(depth_for(boxes.size()), left), tl);
     std::vector<uint32_t> tl_inst(tl.order.size() ? tl.order.size() : 1, 0u);
     for (size_t k = 0; k < tl.order.size(); k++) tl_inst[k] = box_inst[tl.order[k]];
     const uint32_t need = tl.max_stack + srl::kLeafMax + s->blas_stack + 1u;     // top-level entries + pending instances of a leaf + marker + mesh tree
