@@ -226,8 +226,10 @@ def test_textured_closest_hit_payloads(rt, oracle):
     assert len(np.unique(pl["material_info"][hit])) > 500
 
 
-def test_any_hit_alpha_test_equals_oracle(rt, oracle):
-    """K5, any_hit.slang:11-43, on both sides. The reference never runs the shader (OPAQUE geometry, blas.rs:276; alpha_mode
+@pytest.mark.parametrize("instancing", ["flat", "two_level"])
+def test_any_hit_alpha_test_equals_oracle(rt, oracle, instancing):
+    """K5, any_hit.slang:11-43, on both sides (and in both forms of the structure: the two-level one finds a hit's shade record
+    through the instance's mesh). The reference never runs the shader (OPAQUE geometry, blas.rs:276; alpha_mode
     forced 0, material.rs:74), so the materials are given MASK modes by hand: textured with a varying alpha channel, an RGB
     image (alpha widened to 0, utils.rs:27-43), untextured (the base-colour factor's alpha is the fallback), and
     alpha_mode == 0 (returns before sampling)."""
@@ -244,7 +246,8 @@ def test_any_hit_alpha_test_equals_oracle(rt, oracle):
         if k % 3 == 1:
             bc = m.material["base_color_value"].copy(); bc[..., 3] = 0.3; m.material["base_color_value"] = bc
     osc = oracle.OracleScene().load(desc)
-    gsc = rt.Scene(0).load(desc)
+    gsc = rt.Scene(0, instancing=instancing).load(desc)
+    assert gsc.two_level() == (instancing == "two_level")
     rays = np.concatenate([camera_rays(oracle, desc, 200, 120), random_rays(30000, 35, box=((-8, 0.1, -17), (8, 6.5, 17)))])
     hits_t = gsc.trace_closest(rt.rays_to_device(rays), len(rays))
     hits = rt.hits_from_device(hits_t)

@@ -188,3 +188,39 @@ def test_two_level_holds_ten_thousand_instances_of_a_ten_thousand_triangle_mesh(
     assert used < (1 << 30), "two-level scene uses %.1f MB of HBM" % (used / 2 ** 20)
     print("10 000 x 10 080 triangles: first build %.0f ms, instance update %.0f ms, %.1f MB of HBM, %d nodes" % (t_first * 1e3, t_update * 1e3, used / 2 ** 20, st.n_nodes))
     assert t_update < 1.0
+
+
+def test_two_level_renderer_and_instrumented_variants(rt, oracle, monkeypatch):
+    """The Renderer facade in the two-level form (SR_INSTANCING is read when a scene is created): the reference's png example
+    at a reduced extent, 16 frames + 3 more (quiet frames: AsState settles with a rebuild of the top-level tree), byte for byte the
+    one-level renderer's output. Then the instrumented kernel variants of the two-level walk count box and triangle tests."""
+    from test_gpu_parity import PNG_EXAMPLE_CAMERA, REF_ASSET_DIR
+    noise = rt.decode_image_rgba8(open(os.path.join(REF_ASSET_DIR, "noise.png"), "rb").read())
+    out = {}
+    for form in ("flat", "two_level"):
+        monkeypatch.setenv("SR_INSTANCING", form)
+        r = rt.Renderer((320, 240))
+        r.set_blue_noise(noise)
+        _, inst = r.load_gltf(os.path.join(REF_ASSET_DIR, "ReflectionRoom.glb"))
+        img = r.render_to_host_memory(PNG_EXAMPLE_CAMERA, inst)
+        for _ in range(3):
+            fr = r.render(PNG_EXAMPLE_CAMERA, inst)
+        r.wait_frame(fr)
+        out[form] = img
+        r.close()
+    monkeypatch.delenv("SR_INSTANCING")
+    assert (out["flat"] == out["two_level"]).all() and len(np.unique(out["flat"].reshape(-1, 4), axis=0)) > 500
+    desc = small_atrium()
+    sc = rt.Scene(0, instancing="two_level").load(desc)
+    fr = rt.DeviceFrame(160, 96, scenes.white_noise_rgba8())
+    m = rt.camera_matrices(desc.camera_pos, desc.camera_target, desc.fov_y, 160, 96)
+    plain = []
+    for instrumented in (False, True):
+        sc.set_instrumented(instrumented)
+        sc.reset_counters()
+        sc.trace_ris(fr, m, 0); sc.trace_final(fr, m, 0)
+        c = sc.counters()
+        plain.append((c.closest_queries, c.any_queries, fr.host()["raw_color"].copy()))
+        assert (c.boxes_tested > 0 and c.tris_tested > 0) == instrumented
+    assert plain[0][:2] == plain[1][:2]
+    assert_bits_equal(plain[0][2], plain[1][2], "instrumented two-level variant")
