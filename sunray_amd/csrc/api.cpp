@@ -559,7 +559,7 @@ int full_build(SrScene* s);
 // resource_manager.rs:236-251). The one-level form copies every instance's triangles into one world-space tree — memory and
 // update cost O(instances x triangles). This form keeps one tree per MESH in object space and a top-level tree over padded
 // instance boxes: a changed instance list costs a top-level rebuild (host, O(instances log instances)) and one 128-byte record
-// per instance, whatever the meshes hold. Hits are those of the one-level form bit for bit (traverse.h: traverse_tl).
+// per instance, whatever the meshes hold. Hits are those of the one-level form bit for bit (traverse.h: traverse_ws with TL = true).
 constexpr uint32_t kTlStackCap = 47;     // LDS stack entries a two-level walk may need (top-level + pending instances of a leaf + marker + mesh
                                          // tree): with the spare level and the 8 work rows, 56 rows = 56 KB for the 256-thread queue tracers
 
@@ -1119,7 +1119,7 @@ static int trace_queue(SrScene* s, const SrRay* rays, uint32_t n, SrHit* hits, u
     hipStream_t st = (hipStream_t)stream;
     // every launch gets a queue head of its own from a small ring, so launches on different streams never share one
     uint32_t* queue_head = (uint32_t*)((char*)s->d_misc.p + kQueueHeadOffset + 16 * (s->queue_head_clock++ % kQueueHeads));
-    const int lds_per_block = srk_lds_rows(s->stack_entries) * 256 * 4;
+    const int lds_per_block = srk_lds_rows(s->stack_entries, s->two_level ? 1 : 0) * 256 * 4;
     int per_cu = std::max(1, std::min(8, 160 * 1024 / lds_per_block));  // persistent grid = LDS-limited residency
     if (const char* e = getenv("SR_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));   // tuning switch
     const int n_blocks = s->n_cus * per_cu;

@@ -44,7 +44,7 @@ int srk_launch_shade(const srd::DevScene& sc, const SrHit* hits, uint32_t n, SrR
 int srk_launch_any_hit(const srd::DevScene& sc, const SrHit* hits, uint32_t n, uint32_t* ignored, hipStream_t stream);
 int srk_launch_pass(const srd::PassArgs& args, int which, int stats, int textured, int two_level, int stack_entries, hipStream_t stream);
 // Tile schedule of the next launch from this launch's costs: per XCD band, tiles in descending cost (64 buckets).
-int srk_lds_rows(int stack_entries);
+int srk_lds_rows(int stack_entries, int two_level);
 uint32_t srk_pass_tile_count(uint32_t width, uint32_t rows);
 uint32_t srk_pass_order_cap(uint32_t width, uint32_t rows);
 int srk_launch_tile_order(const uint32_t* tile_cost, uint32_t* tile_order, uint32_t width, uint32_t rows, hipStream_t stream);

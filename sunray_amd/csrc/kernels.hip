@@ -19,7 +19,7 @@ namespace srd {
 constexpr int kBlock = 256;        // ray-queue and shade kernels
 constexpr int kPassBlock = 64;     // the two pass megakernels: one wave = one workgroup = one 8x8 pixel tile
 constexpr int kPassTile = 8;
-constexpr int kLdsExtraRows = kWsRows;   // LDS rows of the work-stealing traversal in front of the stack levels
+static int lds_extra_rows(int two_level) { return two_level ? kWsRowsTl : kWsRows; }   // LDS rows of the work-stealing traversal in front of the stack levels
 constexpr int kPassWaves = 4;      // __launch_bounds__ second argument on HIP: waves per SIMD (4 -> VGPR budget 128)
 
 // Wave-wide sum, then one atomic per wave (rays are counted, not estimated: SURVEY.md §8d).
@@ -52,8 +52,7 @@ __global__ __launch_bounds__(kBlock) void trace_queue_kernel(DevScene sc, const 
             const float4 ra = reinterpret_cast<const float4*>(rays)[ic * 2 + 0];
             const float4 rb = reinterpret_cast<const float4*>(rays)[ic * 2 + 1];
             TravHit h;
-            const bool found = TL ? traverse_tl<ANY, STATS>(sc, i < n, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), ra.w, rb.w, h, stack, kBlock, st)
-                                  : traverse_ws<ANY, STATS>(sc, i < n, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), ra.w, rb.w, h, stack, kBlock, st);
+            const bool found = traverse_ws<ANY, STATS, TL>(sc, i < n, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), ra.w, rb.w, h, stack, kBlock, st);
             if (i < n) {
             n_queries++;
             if (ANY) occluded[i] = found ? 1u : 0u;
@@ -124,11 +123,10 @@ struct PixelCtx {
     uint32_t n_reused = 0;   // closest-hit queries of the reference answered from the primary-hit hand-off instead of a traversal
 };
 
-// TraceRay of the passes: V bit 2 selects the two-level walk (traverse_tl) over the one-level one with work stealing (traverse_ws)
+// TraceRay of the passes: V bit 0 = traversal statistics, V bit 2 = the two-level form of the structure
 template <int V, bool ANY>
 SRD bool trace_ray(PixelCtx& cx, bool want, f3 o, f3 d, float tmin, float tmax, TravHit& h) {
-    if constexpr ((V & 4) != 0) return traverse_tl<ANY, (V & 1) != 0>(cx.a.sc, want, o, d, tmin, tmax, h, cx.stack, kPassBlock, cx.st);
-    else return traverse_ws<ANY, (V & 1) != 0>(cx.a.sc, want, o, d, tmin, tmax, h, cx.stack, kPassBlock, cx.st);
+    return traverse_ws<ANY, (V & 1) != 0, (V & 4) != 0>(cx.a.sc, want, o, d, tmin, tmax, h, cx.stack, kPassBlock, cx.st);
 }
 template <int V>
 SRD Payload trace_closest_shaded(PixelCtx& cx, f3 o, f3 d, float tmin, float tmax) {
@@ -976,7 +974,7 @@ int srk_launch_trace(const DevScene& sc, const SrRay* rays, uint32_t n, SrHit* h
     if (e != hipSuccess) return (int)e;
     if (n == 0) return 0;
     dim3 grid(n_blocks), block(kBlock);
-    const size_t lds = (size_t)(stack_entries + kLdsExtraRows) * kBlock * sizeof(int);
+    const size_t lds = (size_t)(stack_entries + lds_extra_rows(two_level)) * kBlock * sizeof(int);
     const int v = (any ? 1 : 0) | (stats ? 2 : 0) | (two_level ? 4 : 0);
     switch (v) {
         case 0: trace_queue_kernel<false, false, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
@@ -1013,7 +1011,7 @@ int srk_launch_pass(const PassArgs& args_in, int which, int stats, int textured,
     const uint32_t n_tiles = args.tiles_x * args.tiles_y;
     if (n_tiles == 0) return 0;
     dim3 grid(args.order_cap * 8), block(kPassBlock);
-    const size_t lds = (size_t)(stack_entries + kLdsExtraRows) * kPassBlock * sizeof(int);
+    const size_t lds = (size_t)(stack_entries + lds_extra_rows(two_level)) * kPassBlock * sizeof(int);
     const int v = (stats ? 1 : 0) | (textured ? 2 : 0) | (two_level ? 4 : 0);
     if (which == 0) {
         switch (v) {
@@ -1041,7 +1039,7 @@ int srk_launch_pass(const PassArgs& args_in, int which, int stats, int textured,
     return (int)hipGetLastError();
 }
 
-int srk_lds_rows(int stack_entries) { return stack_entries + kLdsExtraRows; }   // LDS rows (of one int per thread) a block needs
+int srk_lds_rows(int stack_entries, int two_level) { return stack_entries + lds_extra_rows(two_level); }   // LDS rows (of one int per thread) a block needs
 
 uint32_t srk_pass_tile_count(uint32_t width, uint32_t rows) { return ((width + kPassTile - 1) / kPassTile) * ((rows + kPassTile - 1) / kPassTile); }
 

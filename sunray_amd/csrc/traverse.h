@@ -194,17 +194,41 @@ SRD int pick(int4 c, uint32_t i) {   // two levels of selects (v_cndmask), no br
 // depend on who found it — and the payload (t, u, v, slot) written by whoever holds the minimum. The key also carries
 // the best t to every lane working for the ray (culling bound) and, for existence queries, the "found" flag.
 // Box culling is conservative, so splitting a walk cannot change its result.
-// LDS: kWsRows rows of `stride` ints in front of the stack levels: keys (2 rows), lane exchange (1), payload (4).
+// LDS: kWsRows rows of `stride` ints in front of the stack levels: keys (2 rows), lane exchange (1), payload (4; the two-level
+// form adds the instance: 5).
+//
+// TL = the two-level form of the structure (optional, for instance-heavy scenes; the reference's TLAS over BLASes, tlas.rs:155-191,
+// resource_manager.rs:236-251). `nodes` is then the top-level tree over padded world-space instance boxes. Entering an instance
+// transforms the ray into the mesh's object space for the BOX tests only (the parameter t is the same in both spaces, the
+// direction is not re-normalised). A leaf's triangles are brought to world space on the fly — the same transform_point
+// operations that flatten them in the one-level form — and tested against the world-space ray, so a hit carries exactly the bits
+// of the one-level form; the tie rule (smallest t, then lowest global triangle index = instance-major) is unchanged. Culling
+// stays conservative through the per-instance padding (DevTlInstance::pad_*). A lane's stack holds top-level entries below
+// index `lsp` and the current instance's entries from there; the instance is left when the stack falls back to `lsp` — after
+// the lane's postponed leaf, which belongs to it, has been tested. Work stealing hands over the bottom entry as before: a
+// top-level one with the world-space ray, or — once the donor has none left — one of the instance with its object-space ray.
 // ---------------------------------------------------------------------------------------------
-constexpr int kWsRows = 7;
+constexpr int kWsRows = 7, kWsRowsTl = 8;
 SRD uint32_t ord_f32(float f) { const uint32_t b = __float_as_uint(f + 0.0f); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
 SRD float unord_f32(uint32_t k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
 SRD uint32_t lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
-
-#define SR_WS_POP() (sp == sb ? kSentinel : stack_base[(--sp) * stride])
+struct NodePlanesTl {
+    uint32_t nx, ny, nz, fx, fy, fz;
+    float ax, ay, az;
+    float bnx, bny, bnz, bfx, bfy, bfz;   // near / far offsets: (origin - o) * inv -/+ pad * |inv|
+};
+template <int C>
+SRD bool child_hit_tl(const NodePlanesTl& p, float t_lo, float t_hi, float& tnear) {
+    const float t0 = fmaxf(fmaxf(fmaf(plane_q<C>(p.nx), p.ax, p.bnx), fmaf(plane_q<C>(p.ny), p.ay, p.bny)),
+                           fmaxf(fmaf(plane_q<C>(p.nz), p.az, p.bnz), t_lo));
+    float far = fminf(fminf(fmaf(plane_q<C>(p.fx), p.ax, p.bfx), fmaf(plane_q<C>(p.fy), p.ay, p.bfy)), fmaf(plane_q<C>(p.fz), p.az, p.bfz));
+    far = fmaf(fabsf(far), 5e-7f, far);
+    tnear = t0;
+    return t0 <= fminf(far, t_hi);
+}
 
 // Every lane of the wave that is active at the call site takes part; `want` = this lane has a ray of its own.
-template <bool ANY, bool STATS>
+template <bool ANY, bool STATS, bool TL = false>
 SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, float tmax, TravHit& hit, int* lds_col, int stride, TravStats& st) {
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ tris = sc.tris;
@@ -212,28 +236,48 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
     int* const blk = lds_col - tid;
     unsigned long long* const keys = reinterpret_cast<unsigned long long*>(blk);   // rows 0-1: one u64 per thread
     int* const xch = blk + 2 * stride + (tid & ~63u);                               // row 2: this wave's 64 exchange slots
-    int* const pay = blk + 3 * stride;                                              // rows 3-6: t, u, v, slot of the key holder
-    int* const stack_base = lds_col + kWsRows * stride;
+    int* const pay = blk + 3 * stride;                                              // rows 3-6: t, u, v, slot of the key holder (TL: row 7 = instance)
+    int* const stack_base = lds_col + (TL ? kWsRowsTl : kWsRows) * stride;
     keys[tid] = ~0ull;
     uint32_t root = tid;                 // thread whose ray this lane is working for
-    RaySetup rs = ray_setup(o, d);
+    RaySetup rs = ray_setup(o, d);       // of the space being walked
     float t_lo = fminf(tmin, 0.0f) - fabsf(tmin);
     float cull = fmaf(fabsf(tmax), 1e-5f, tmax);
     float best_t = tmax;
     uint32_t best_gid = 0xFFFFFFFFu;
     int sp = 0, sb = 0, leaf = 0;
     int node = want ? 0 : kSentinel;
+    // two-level state (compiled out of the one-level form)
+    bool in_blas = false, pending_leave = false;
+    int lsp = 0;                         // first stack index of the current instance's entries
+    uint32_t inst = 0u;
+    f3 ro = o;                           // origin in the space being walked
+    f3 winv = rs.inv;                    // 1/d of the world-space ray, to come back to without dividing again
+    f3 pad = splat(0.0f);                // box padding of the current instance times |1/d'| per axis
+    auto leave = [&]() { in_blas = false; ro = o; rs.inv = winv; pad = splat(0.0f); };
+    // Next entry of this lane's stack. Two-level: an instance is left when its entries are used up — but not before the lane's
+    // postponed leaf, which belongs to that instance, went through the triangle phase (the lane waits with node == kSentinel).
+    auto pop = [&]() -> int {
+        if (TL) {
+            if (in_blas && sp == lsp) {
+                if (leaf != 0) { pending_leave = true; return kSentinel; }
+                leave();
+            }
+        }
+        return sp == sb ? kSentinel : stack_base[(--sp) * stride];
+    };
     for (;;) {
         // ---- phase top: all participating lanes meet here ----
         if (node != kSentinel) {
             const unsigned long long k = keys[root];
-            if (ANY) { if (k == 0ull) { node = kSentinel; sp = sb; } }        // somebody found an occluder
+            if (ANY) { if (k == 0ull) { node = kSentinel; sp = sb; if (TL) { in_blas = false; } } }        // somebody found an occluder
             else if (k != ~0ull) { const float ts = unord_f32((uint32_t)(k >> 32)); cull = fminf(cull, fmaf(fabsf(ts), 1e-5f, ts)); }
         }
-        if (__builtin_amdgcn_ballot_w64(node != kSentinel) == 0ull) break;
+        if (__builtin_amdgcn_ballot_w64(node != kSentinel || (TL && leaf != 0)) == 0ull) break;
         // ---- node phase: wave-uniform loop, so that lanes without work stay in step and can be handed some ----
         for (;;) {
-            const bool inner = node >= 0 && node != kSentinel;
+            // `inner`: the lane has a node-phase step to do — an inner node, or (two-level) a top-level leaf to enter
+            const bool inner = node != kSentinel && (node >= 0 || (TL && !in_blas));
             if (__builtin_amdgcn_ballot_w64(inner && leaf == 0) == 0ull) break;   // every walking lane holds a (postponed) leaf: on to the triangles
             const bool idle = node == kSentinel && leaf == 0;
             const unsigned long long idle_mask = __builtin_amdgcn_ballot_w64(idle);
@@ -256,6 +300,18 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                     // the zero-direction fix-ups) that the WHOLE wave would issue whenever one lane takes work — the exchange runs
                     // in 28 % / 46 % of the node-loop iterations of the RIS / final pass
                     const float ix = __shfl(rs.inv.x, dl), iy = __shfl(rs.inv.y, dl), iz = __shfl(rs.inv.z, dl);
+                    // two-level: is the donor's bottom entry one of its current instance (it has no top-level entries left)?
+                    // Then the instance and the object-space ray come along; a top-level entry goes with the world-space ray.
+                    bool d_blas = false;
+                    uint32_t d_inst = 0u;
+                    f3 d_ro = splat(0.0f), d_pad = splat(0.0f), d_winv = splat(0.0f);
+                    if (TL) {
+                        d_blas = __shfl((int)(in_blas && sb == lsp), dl) != 0;
+                        d_inst = (uint32_t)__shfl((int)inst, dl);
+                        d_ro = mk3(__shfl(ro.x, dl), __shfl(ro.y, dl), __shfl(ro.z, dl));
+                        d_pad = mk3(__shfl(pad.x, dl), __shfl(pad.y, dl), __shfl(pad.z, dl));
+                        d_winv = mk3(__shfl(winv.x, dl), __shfl(winv.y, dl), __shfl(winv.z, dl));
+                    }
                     if (takes) {
                         node = stack_base[d_sb * stride + (dl - (int)lane)];
                         o = mk3(ox, oy, oz); d = mk3(dx, dy, dz); tmin = d_tmin; tmax = d_tmax; cull = d_cull; root = d_root;
@@ -263,36 +319,78 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                         t_lo = fminf(tmin, 0.0f) - fabsf(tmin);
                         best_t = tmax; best_gid = 0xFFFFFFFFu;
                         sp = 0; sb = 0;
-                        if (node < 0) { leaf = node; node = kSentinel; }   // the stolen entry is a leaf: it waits for the triangle phase
+                        if (TL) {
+                            winv = d_winv; lsp = 0; pending_leave = false;
+                            in_blas = d_blas; inst = d_inst;
+                            if (d_blas) { ro = d_ro; pad = d_pad; }
+                            else { ro = o; rs.inv = d_winv; pad = splat(0.0f); }
+                        }
+                        if (node < 0 && (!TL || in_blas)) { leaf = node; node = kSentinel; }   // the stolen entry is a leaf: it waits for the triangle phase
                     }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    if (gives) sb++;
+                    if (gives) { if (TL) { if (in_blas && sb == lsp) lsp++; } sb++; }
                 }
             }
-            if (node >= 0 && node != kSentinel) {
-                const float4* n = nodes + (size_t)node * 4;
+            if (TL && node != kSentinel && node < 0 && !in_blas) {
+                // top-level leaf: enter its first instance, the others wait below as leaves of one
+                const uint32_t lv = ~(uint32_t)node;
+                const uint32_t first = lv >> 3, cnt = lv & 7u;
+                if (cnt == 0u) node = pop();
+                else {
+                    for (uint32_t k = 1; k < cnt; k++) { stack_base[sp * stride] = (int)~(((first + k) << 3) | 1u); sp++; }
+                    inst = sc.tl_inst[first];
+                    const float4* q = reinterpret_cast<const float4*>(sc.tl_instances + inst);
+                    const float4 r0 = q[0], r1 = q[1], r2 = q[2], m6 = q[6];
+                    ro = mk3(((r0.x * o.x + r0.y * o.y) + r0.z * o.z) + r0.w, ((r1.x * o.x + r1.y * o.y) + r1.z * o.z) + r1.w,
+                             ((r2.x * o.x + r2.y * o.y) + r2.z * o.z) + r2.w);
+                    const f3 rd = mk3((r0.x * d.x + r0.y * d.y) + r0.z * d.z, (r1.x * d.x + r1.y * d.y) + r1.z * d.z, (r2.x * d.x + r2.y * d.y) + r2.z * d.z);
+                    rs = ray_setup(ro, rd);
+                    const float pd = fmaf(m6.z, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)), m6.w);
+                    pad = mk3(pd * fabsf(rs.inv.x), pd * fabsf(rs.inv.y), pd * fabsf(rs.inv.z));
+                    lsp = sp;
+                    in_blas = true;
+                    node = (int)__float_as_uint(m6.x);
+                }
+            } else if (node >= 0 && node != kSentinel) {
+                const float4* n = ((TL && in_blas) ? sc.blas_nodes : nodes) + (size_t)node * 4;
                 const float4 h0 = n[0], q1 = n[1], q2 = n[2], qc = n[3];
                 const int4 child = make_int4(__float_as_int(qc.x), __float_as_int(qc.y), __float_as_int(qc.z), __float_as_int(qc.w));
                 if (STATS) st.boxes += 4;
                 const uint32_t ex = __float_as_uint(h0.w);
                 const uint32_t LX = __float_as_uint(q1.x), LY = __float_as_uint(q1.y), LZ = __float_as_uint(q1.z);
                 const uint32_t HX = __float_as_uint(q1.w), HY = __float_as_uint(q2.x), HZ = __float_as_uint(q2.y);
-                NodePlanes p;
                 // The ray's direction signs (the NEAR plane of a slab is the upper one for a negative direction) are re-derived
                 // from inv here, three v_cmp: kept as lane masks across the loop, which the stealing path updates divergently,
                 // they cost the compiler ~18 s_and / s_andn2 / s_or per step (-35 SALU in the kernel, frame -1.5 %).
                 const bool sgx = __float_as_int(rs.inv.x) < 0, sgy = __float_as_int(rs.inv.y) < 0, sgz = __float_as_int(rs.inv.z) < 0;
-                p.nx = sgx ? HX : LX; p.fx = sgx ? LX : HX;
-                p.ny = sgy ? HY : LY; p.fy = sgy ? LY : HY;
-                p.nz = sgz ? HZ : LZ; p.fz = sgz ? LZ : HZ;
-                p.ax = __uint_as_float((ex & 0xFFu) << 23) * rs.inv.x; p.ay = __uint_as_float(((ex >> 8) & 0xFFu) << 23) * rs.inv.y;
-                p.az = __uint_as_float(((ex >> 16) & 0xFFu) << 23) * rs.inv.z;
-                p.bx = (h0.x - o.x) * rs.inv.x; p.by = (h0.y - o.y) * rs.inv.y; p.bz = (h0.z - o.z) * rs.inv.z;
                 float n0, n1, n2, n3;
-                const bool b0 = child_hit<0>(p, t_lo, cull, n0);
-                const bool b1 = child_hit<1>(p, t_lo, cull, n1);
-                const bool b2 = child_hit<2>(p, t_lo, cull, n2);
-                const bool b3 = child_hit<3>(p, t_lo, cull, n3);
+                bool b0, b1, b2, b3;
+                if (TL) {
+                    NodePlanesTl p;
+                    p.nx = sgx ? HX : LX; p.fx = sgx ? LX : HX;
+                    p.ny = sgy ? HY : LY; p.fy = sgy ? LY : HY;
+                    p.nz = sgz ? HZ : LZ; p.fz = sgz ? LZ : HZ;
+                    p.ax = __uint_as_float((ex & 0xFFu) << 23) * rs.inv.x; p.ay = __uint_as_float(((ex >> 8) & 0xFFu) << 23) * rs.inv.y;
+                    p.az = __uint_as_float(((ex >> 16) & 0xFFu) << 23) * rs.inv.z;
+                    const float bx = (h0.x - ro.x) * rs.inv.x, by = (h0.y - ro.y) * rs.inv.y, bz = (h0.z - ro.z) * rs.inv.z;
+                    p.bnx = bx - pad.x; p.bfx = bx + pad.x; p.bny = by - pad.y; p.bfy = by + pad.y; p.bnz = bz - pad.z; p.bfz = bz + pad.z;
+                    b0 = child_hit_tl<0>(p, t_lo, cull, n0);
+                    b1 = child_hit_tl<1>(p, t_lo, cull, n1);
+                    b2 = child_hit_tl<2>(p, t_lo, cull, n2);
+                    b3 = child_hit_tl<3>(p, t_lo, cull, n3);
+                } else {
+                    NodePlanes p;
+                    p.nx = sgx ? HX : LX; p.fx = sgx ? LX : HX;
+                    p.ny = sgy ? HY : LY; p.fy = sgy ? LY : HY;
+                    p.nz = sgz ? HZ : LZ; p.fz = sgz ? LZ : HZ;
+                    p.ax = __uint_as_float((ex & 0xFFu) << 23) * rs.inv.x; p.ay = __uint_as_float(((ex >> 8) & 0xFFu) << 23) * rs.inv.y;
+                    p.az = __uint_as_float(((ex >> 16) & 0xFFu) << 23) * rs.inv.z;
+                    p.bx = (h0.x - o.x) * rs.inv.x; p.by = (h0.y - o.y) * rs.inv.y; p.bz = (h0.z - o.z) * rs.inv.z;
+                    b0 = child_hit<0>(p, t_lo, cull, n0);
+                    b1 = child_hit<1>(p, t_lo, cull, n1);
+                    b2 = child_hit<2>(p, t_lo, cull, n2);
+                    b3 = child_hit<3>(p, t_lo, cull, n3);
+                }
                 uint32_t k0, k1, k2, k3;
                 if (ANY) {
                     // Existence queries visit the hit child whose entry point is FARTHEST first (closest-hit queries need the
@@ -318,24 +416,48 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                 stack_base[sp * stride] = child.y; sp += (b1 && k1 != kmin) ? 1 : 0;
                 stack_base[sp * stride] = child.z; sp += (b2 && k2 != kmin) ? 1 : 0;
                 stack_base[sp * stride] = child.w; sp += (b3 && k3 != kmin) ? 1 : 0;
-                node = (kmin != 0xFFFFFFFFu) ? pick(child, slot) : SR_WS_POP();
-                if (node < 0 && leaf == 0) { leaf = node; node = SR_WS_POP(); }
+                node = (kmin != 0xFFFFFFFFu) ? pick(child, slot) : pop();
+                if (node < 0 && node != kSentinel && leaf == 0 && (!TL || in_blas)) { leaf = node; node = pop(); }
             }
         }
         while (leaf != 0) {
             const uint32_t lv = ~(uint32_t)leaf;
             const uint32_t slot = lv >> 3, cnt = lv & 7u;
             leaf = cnt > 1u ? (int)~(((slot + 1u) << 3) | (cnt - 1u)) : 0;
-            if (leaf == 0 && node < 0) { leaf = node; node = SR_WS_POP(); }
+            // (two-level: `inst` is still the leaf's instance — the lane cannot have left it with the leaf pending)
+            const uint32_t leaf_inst = inst;
+            if (leaf == 0) {
+                if (TL && pending_leave) { pending_leave = false; leave(); node = pop(); }
+                else if (node < 0 && (!TL || in_blas)) { leaf = node; node = pop(); }
+            }
             if (cnt == 0u) continue;
             const float4 t0 = tris[(size_t)slot * 3 + 0];
             const float4 t1 = tris[(size_t)slot * 3 + 1];
             const float4 t2 = tris[(size_t)slot * 3 + 2];
             float t, u, v;
             if (STATS) st.tris += 1;
-            if (intersect_tri(o, d, mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), tmin, tmax, t, u, v)) {
-                if (ANY) { keys[root] = 0ull; node = kSentinel; sp = sb; leaf = 0; break; }
-                const uint32_t gid = __float_as_uint(t2.y);
+            bool is_hit;
+            uint32_t gid;
+            if (TL) {
+                // object-space v0, v1, v2 -> world space with transform_point (rt_utils.slang:278-281), exactly as the one-level form
+                // flattens a triangle; the test itself runs on the world-space ray
+                const float4* q = reinterpret_cast<const float4*>(sc.tl_instances + leaf_inst);
+                const float4 m0 = q[3], m1 = q[4], m2 = q[5];
+                const f3 a = mk3(t0.x, t0.y, t0.z), b = mk3(t0.w, t1.x, t1.y), c = mk3(t1.z, t1.w, t2.x);
+                const f3 wa = mk3(((m0.x * a.x + m0.y * a.y) + m0.z * a.z) + m0.w * 1.0f, ((m1.x * a.x + m1.y * a.y) + m1.z * a.z) + m1.w * 1.0f,
+                                  ((m2.x * a.x + m2.y * a.y) + m2.z * a.z) + m2.w * 1.0f);
+                const f3 wb = mk3(((m0.x * b.x + m0.y * b.y) + m0.z * b.z) + m0.w * 1.0f, ((m1.x * b.x + m1.y * b.y) + m1.z * b.z) + m1.w * 1.0f,
+                                  ((m2.x * b.x + m2.y * b.y) + m2.z * b.z) + m2.w * 1.0f);
+                const f3 wc = mk3(((m0.x * c.x + m0.y * c.y) + m0.z * c.z) + m0.w * 1.0f, ((m1.x * c.x + m1.y * c.y) + m1.z * c.z) + m1.w * 1.0f,
+                                  ((m2.x * c.x + m2.y * c.y) + m2.z * c.z) + m2.w * 1.0f);
+                is_hit = intersect_tri(o, d, wa, wb - wa, wc - wa, tmin, tmax, t, u, v);
+                gid = sc.tl_instances[leaf_inst].tri_offset + __float_as_uint(t2.y);
+            } else {
+                is_hit = intersect_tri(o, d, mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), tmin, tmax, t, u, v);
+                gid = __float_as_uint(t2.y);
+            }
+            if (is_hit) {
+                if (ANY) { keys[root] = 0ull; node = kSentinel; sp = sb; leaf = 0; if (TL) { in_blas = false; pending_leave = false; } break; }
                 if (t < best_t || (t == best_t && gid < best_gid)) {
                     best_t = t; best_gid = gid;
                     cull = fminf(cull, fmaf(fabsf(t), 1e-5f, t));
@@ -344,6 +466,7 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                     if (keys[root] == key) {   // this lane holds the minimum: its payload stands
                         pay[0 * stride + root] = __float_as_int(t); pay[1 * stride + root] = __float_as_int(u);
                         pay[2 * stride + root] = __float_as_int(v); pay[3 * stride + root] = (int)slot;
+                        if (TL) pay[4 * stride + root] = (int)leaf_inst;
                     }
                 }
             }
@@ -357,143 +480,11 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
         hit.gid = (uint32_t)k;
         hit.t = __int_as_float(pay[0 * stride + tid]); hit.u = __int_as_float(pay[1 * stride + tid]);
         hit.v = __int_as_float(pay[2 * stride + tid]); hit.slot = (uint32_t)pay[3 * stride + tid];
+        if (TL) hit.inst = (uint32_t)pay[4 * stride + tid];
     }
     return k != ~0ull;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Two-level walk (optional form of the structure for instance-heavy scenes; the reference's TLAS over BLASes, tlas.rs:155-191,
-// resource_manager.rs:236-251). The top-level tree holds padded world-space boxes of the instances; entering an instance
-// transforms the ray into the mesh's object space for the BOX tests only (the parameter t is the same in both spaces, the
-// direction is not re-normalised). A leaf's triangles are brought to world space on the fly — the same transform_point
-// operations that flatten them in the one-level form — and tested against the world-space ray, so a hit carries exactly the
-// bits of the flattened form; the tie rule (smallest t, then lowest global triangle index = instance-major) is unchanged.
-// Culling stays conservative through the per-instance padding (DevTlInstance::pad_*). One lane = one ray, no work stealing:
-// a stolen subtree would need its instance. Stack: top-level entries below, a kLeave marker, then the mesh's entries.
-// ---------------------------------------------------------------------------------------------
-constexpr int kLeave = 0x7ffffffe;
-struct NodePlanesTl {
-    uint32_t nx, ny, nz, fx, fy, fz;
-    float ax, ay, az;
-    float bnx, bny, bnz, bfx, bfy, bfz;   // near / far offsets: (origin - o) * inv -/+ pad * |inv|
-};
-template <int C>
-SRD bool child_hit_tl(const NodePlanesTl& p, float t_lo, float t_hi, float& tnear) {
-    const float t0 = fmaxf(fmaxf(fmaf(plane_q<C>(p.nx), p.ax, p.bnx), fmaf(plane_q<C>(p.ny), p.ay, p.bny)),
-                           fmaxf(fmaf(plane_q<C>(p.nz), p.az, p.bnz), t_lo));
-    float far = fminf(fminf(fmaf(plane_q<C>(p.fx), p.ax, p.bfx), fmaf(plane_q<C>(p.fy), p.ay, p.bfy)), fmaf(plane_q<C>(p.fz), p.az, p.bfz));
-    far = fmaf(fabsf(far), 5e-7f, far);
-    tnear = t0;
-    return t0 <= fminf(far, t_hi);
-}
-#define SR_TL_POP() (sp == 0 ? kSentinel : stack_base[(--sp) * stride])
-template <bool ANY, bool STATS>
-SRD bool traverse_tl(const DevScene& sc, bool want, f3 o, f3 d, float tmin, float tmax, TravHit& hit, int* lds_col, int stride, TravStats& st) {
-    const float4* __restrict__ tris = sc.tris;
-    int* const stack_base = lds_col + kWsRows * stride;
-    const float t_lo = fminf(tmin, 0.0f) - fabsf(tmin);
-    float cull = fmaf(fabsf(tmax), 1e-5f, tmax);
-    float best_t = tmax, best_u = 0.0f, best_v = 0.0f;
-    uint32_t best_gid = 0xFFFFFFFFu, best_slot = 0u, best_inst = 0u;
-    const float o_mag = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-    int sp = 0;
-    int node = want ? 0 : kSentinel;
-    bool in_blas = false, found = false;
-    uint32_t inst = 0u;
-    f3 ro = o;                                // ray of the space being walked (direction enters through inv only)
-    RaySetup rs = ray_setup(o, d);
-    f3 pad = splat(0.0f);                     // padding of the current instance times |1/d| per axis
-    while (node != kSentinel) {
-        if (node == kLeave) {                 // the instance is done: back to the world-space ray
-            in_blas = false; ro = o; rs = ray_setup(o, d); pad = splat(0.0f);
-            node = SR_TL_POP();
-        } else if (node >= 0) {
-            const float4* n = (in_blas ? sc.blas_nodes : sc.nodes) + (size_t)node * 4;
-            const float4 h0 = n[0], q1 = n[1], q2 = n[2], qc = n[3];
-            const int4 child = make_int4(__float_as_int(qc.x), __float_as_int(qc.y), __float_as_int(qc.z), __float_as_int(qc.w));
-            if (STATS) st.boxes += 4;
-            const uint32_t ex = __float_as_uint(h0.w);
-            const uint32_t LX = __float_as_uint(q1.x), LY = __float_as_uint(q1.y), LZ = __float_as_uint(q1.z);
-            const uint32_t HX = __float_as_uint(q1.w), HY = __float_as_uint(q2.x), HZ = __float_as_uint(q2.y);
-            NodePlanesTl p;
-            const bool sgx = __float_as_int(rs.inv.x) < 0, sgy = __float_as_int(rs.inv.y) < 0, sgz = __float_as_int(rs.inv.z) < 0;
-            p.nx = sgx ? HX : LX; p.fx = sgx ? LX : HX;
-            p.ny = sgy ? HY : LY; p.fy = sgy ? LY : HY;
-            p.nz = sgz ? HZ : LZ; p.fz = sgz ? LZ : HZ;
-            p.ax = __uint_as_float((ex & 0xFFu) << 23) * rs.inv.x; p.ay = __uint_as_float(((ex >> 8) & 0xFFu) << 23) * rs.inv.y;
-            p.az = __uint_as_float(((ex >> 16) & 0xFFu) << 23) * rs.inv.z;
-            const float bx = (h0.x - ro.x) * rs.inv.x, by = (h0.y - ro.y) * rs.inv.y, bz = (h0.z - ro.z) * rs.inv.z;
-            p.bnx = bx - pad.x; p.bfx = bx + pad.x; p.bny = by - pad.y; p.bfy = by + pad.y; p.bnz = bz - pad.z; p.bfz = bz + pad.z;
-            float n0, n1, n2, n3;
-            const bool b0 = child_hit_tl<0>(p, t_lo, cull, n0);
-            const bool b1 = child_hit_tl<1>(p, t_lo, cull, n1);
-            const bool b2 = child_hit_tl<2>(p, t_lo, cull, n2);
-            const bool b3 = child_hit_tl<3>(p, t_lo, cull, n3);
-            uint32_t k0, k1, k2, k3;      // nearest child first (existence queries too: no stealing here, so nothing to leave behind)
-            k0 = b0 ? ((__float_as_uint(fmaxf(n0, 0.0f)) & ~3u) | 0u) : 0xFFFFFFFFu;
-            k1 = b1 ? ((__float_as_uint(fmaxf(n1, 0.0f)) & ~3u) | 1u) : 0xFFFFFFFFu;
-            k2 = b2 ? ((__float_as_uint(fmaxf(n2, 0.0f)) & ~3u) | 2u) : 0xFFFFFFFFu;
-            k3 = b3 ? ((__float_as_uint(fmaxf(n3, 0.0f)) & ~3u) | 3u) : 0xFFFFFFFFu;
-            const uint32_t kmin = min(min(k0, k1), min(k2, k3));
-            stack_base[sp * stride] = child.x; sp += (b0 && k0 != kmin) ? 1 : 0;
-            stack_base[sp * stride] = child.y; sp += (b1 && k1 != kmin) ? 1 : 0;
-            stack_base[sp * stride] = child.z; sp += (b2 && k2 != kmin) ? 1 : 0;
-            stack_base[sp * stride] = child.w; sp += (b3 && k3 != kmin) ? 1 : 0;
-            node = (kmin != 0xFFFFFFFFu) ? pick(child, kmin & 3u) : SR_TL_POP();
-        } else {
-            const uint32_t lv = ~(uint32_t)node;
-            const uint32_t first = lv >> 3, cnt = lv & 7u;
-            if (!in_blas) {
-                // top-level leaf: enter its first instance, the others wait on the stack as leaves of one
-                if (cnt == 0u) { node = SR_TL_POP(); continue; }
-                for (uint32_t k = 1; k < cnt; k++) { stack_base[sp * stride] = (int)~(((first + k) << 3) | 1u); sp++; }
-                inst = sc.tl_inst[first];
-                const float4* q = reinterpret_cast<const float4*>(sc.tl_instances + inst);
-                const float4 r0 = q[0], r1 = q[1], r2 = q[2], m6 = q[6];
-                ro = mk3(((r0.x * o.x + r0.y * o.y) + r0.z * o.z) + r0.w, ((r1.x * o.x + r1.y * o.y) + r1.z * o.z) + r1.w,
-                         ((r2.x * o.x + r2.y * o.y) + r2.z * o.z) + r2.w);
-                const f3 rd = mk3((r0.x * d.x + r0.y * d.y) + r0.z * d.z, (r1.x * d.x + r1.y * d.y) + r1.z * d.z, (r2.x * d.x + r2.y * d.y) + r2.z * d.z);
-                rs = ray_setup(ro, rd);
-                const float pd = fmaf(m6.z, o_mag, m6.w);
-                pad = mk3(pd * fabsf(rs.inv.x), pd * fabsf(rs.inv.y), pd * fabsf(rs.inv.z));
-                stack_base[sp * stride] = kLeave; sp++;
-                in_blas = true;
-                node = (int)__float_as_uint(m6.x);
-            } else {
-                const float4* q = reinterpret_cast<const float4*>(sc.tl_instances + inst);
-                const float4 m0 = q[3], m1 = q[4], m2 = q[5], m6 = q[6];
-                const uint32_t tri_offset = __float_as_uint(m6.y);
-                for (uint32_t k = 0; k < cnt && !found; k++) {
-                    const uint32_t slot = first + k;
-                    const float4 t0 = tris[(size_t)slot * 3 + 0], t1 = tris[(size_t)slot * 3 + 1], t2 = tris[(size_t)slot * 3 + 2];
-                    if (STATS) st.tris += 1;
-                    // transform_point (rt_utils.slang:278-281), exactly as the one-level form flattens a triangle
-                    const f3 a = mk3(t0.x, t0.y, t0.z), b = mk3(t0.w, t1.x, t1.y), c = mk3(t1.z, t1.w, t2.x);
-                    const f3 wa = mk3(((m0.x * a.x + m0.y * a.y) + m0.z * a.z) + m0.w * 1.0f, ((m1.x * a.x + m1.y * a.y) + m1.z * a.z) + m1.w * 1.0f,
-                                      ((m2.x * a.x + m2.y * a.y) + m2.z * a.z) + m2.w * 1.0f);
-                    const f3 wb = mk3(((m0.x * b.x + m0.y * b.y) + m0.z * b.z) + m0.w * 1.0f, ((m1.x * b.x + m1.y * b.y) + m1.z * b.z) + m1.w * 1.0f,
-                                      ((m2.x * b.x + m2.y * b.y) + m2.z * b.z) + m2.w * 1.0f);
-                    const f3 wc = mk3(((m0.x * c.x + m0.y * c.y) + m0.z * c.z) + m0.w * 1.0f, ((m1.x * c.x + m1.y * c.y) + m1.z * c.z) + m1.w * 1.0f,
-                                      ((m2.x * c.x + m2.y * c.y) + m2.z * c.z) + m2.w * 1.0f);
-                    float t, u, v;
-                    if (intersect_tri(o, d, wa, wb - wa, wc - wa, tmin, tmax, t, u, v)) {
-                        if (ANY) { found = true; break; }
-                        const uint32_t gid = tri_offset + __float_as_uint(t2.y);
-                        if (t < best_t || (t == best_t && gid < best_gid)) {
-                            best_t = t; best_u = u; best_v = v; best_gid = gid; best_slot = slot; best_inst = inst;
-                            cull = fminf(cull, fmaf(fabsf(t), 1e-5f, t));
-                        }
-                    }
-                }
-                node = (ANY && found) ? kSentinel : SR_TL_POP();
-            }
-        }
-    }
-    hit.t = -1.0f; hit.u = 0.0f; hit.v = 0.0f; hit.gid = 0xFFFFFFFFu; hit.slot = 0u; hit.inst = 0u;
-    if (ANY) return found;
-    if (best_gid != 0xFFFFFFFFu) { hit.t = best_t; hit.u = best_u; hit.v = best_v; hit.gid = best_gid; hit.slot = best_slot; hit.inst = best_inst; }
-    return best_gid != 0xFFFFFFFFu;
-}
 // Two-level form: leaf slot and instance of a global triangle index (test hooks only: sr_shade_closest_hit, sr_any_hit_ignores).
 SRD void tl_locate(const DevScene& sc, uint32_t gid, uint32_t& slot, uint32_t& inst) {
     uint32_t lo = 0u, hi = sc.n_instances;
