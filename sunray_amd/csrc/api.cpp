@@ -140,6 +140,9 @@ struct SrScene {
     bool blas_device_current = false;       // the concatenated arrays match the current set of meshes
     bool any_textured_tl = false;
     uint32_t blas_stack = 0;
+    bool tl_baked = false;                  // the device arrays hold baked (world-space) copies of some instances' meshes
+    std::vector<uint32_t> tl_baked_node_base, tl_baked_tri_base;
+    uint64_t tl_blas_nodes = 0, tl_blas_tris = 0;
     DeviceBuffer d_blas_nodes, d_tl_inst, d_tl_instances;
     int instancing = SR_INSTANCING_AUTO;    // sr_scene_set_instancing / SR_INSTANCING in the environment
     bool two_level = false;                 // form of the structure that is built right now
@@ -563,6 +566,8 @@ int full_build(SrScene* s);
 constexpr uint32_t kTlStackCap = 47;     // LDS stack entries a two-level walk may need (top-level + pending instances of a leaf + marker + mesh
                                          // tree): with the spare level and the 8 work rows, 56 rows = 56 KB for the 256-thread queue tracers
 
+constexpr double kTlMaxCondition = 100.0;    // ||W2O||_inf * ||O2W||_inf above which an instance is baked (rotation + uniform scale: <= 3)
+
 uint32_t min_depth_for(uint64_t n_items) {   // binary depth a median split needs to reach leaves of <= 2 items
     uint32_t need = 2;
     for (uint64_t c = (n_items + 1) / 2; c > 1; c = (c + 1) / 2) need++;
@@ -572,16 +577,27 @@ uint32_t depth_for(uint64_t n_items) {       // ... with slack for SAH splits (t
     return std::max(6u, std::min((uint32_t)srd::kMaxBinaryDepth, min_depth_for(n_items) + 6u));
 }
 
-// Object-space tree of one mesh (OpType::SlowBuild of a BLAS, blas.rs:178): same builder, same triangle padding.
-int build_blas(SrScene* s, uint32_t slot) {
-    const srh::HostMesh& mesh = s->meshes[slot];
-    SrScene::HostBlas& b = s->blases[slot];
+// Object-space tree of one mesh (OpType::SlowBuild of a BLAS, blas.rs:178): same builder, same triangle padding. With `bake` the
+// positions are first taken to world space by that transform (transform_point's operation order, as the one-level form flattens):
+// the private copy an instance gets whose transform cannot be inverted (see two_level_build).
+int build_blas(const srh::HostMesh& mesh, uint32_t mesh_slot, const SrTransform* bake, SrScene::HostBlas& b) {
     const uint32_t n = mesh.n_indices / 3;
+    std::vector<float> pos((size_t)mesh.n_vertices * 3);
+    for (uint32_t i = 0; i < mesh.n_vertices; i++) {
+        const float* q = mesh.vertices[i].position;
+        float* w = &pos[(size_t)i * 3];
+        if (bake) {
+            const float* m = bake->m;
+            w[0] = ((m[0] * q[0] + m[1] * q[1]) + m[2] * q[2]) + m[3] * 1.0f;
+            w[1] = ((m[4] * q[0] + m[5] * q[1]) + m[6] * q[2]) + m[7] * 1.0f;
+            w[2] = ((m[8] * q[0] + m[9] * q[1]) + m[10] * q[2]) + m[11] * 1.0f;
+        } else { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; }
+    }
     std::vector<srh::BuildTri> tris(n);
     float max_edge = 0.0f, max_abs = 0.0f;
     for (uint32_t p = 0; p < n; p++) {
         const float* v[3];
-        for (int j = 0; j < 3; j++) v[j] = mesh.vertices[mesh.indices[3 * p + j]].position;
+        for (int j = 0; j < 3; j++) v[j] = &pos[(size_t)mesh.indices[3 * p + j] * 3];
         srh::BuildTri& t = tris[p];
         for (int a = 0; a < 3; a++) {
             t.v0[a] = v[0][a]; t.e1[a] = v[1][a] - v[0][a]; t.e2[a] = v[2][a] - v[0][a];
@@ -604,13 +620,14 @@ int build_blas(SrScene* s, uint32_t slot) {
     for (uint32_t sl = 0; sl < n; sl++) {
         const uint32_t p = bvh.order[sl];
         const SrVertex* v[3];
-        for (int j = 0; j < 3; j++) v[j] = &mesh.vertices[mesh.indices[3 * p + j]];
+        const float* w[3];
+        for (int j = 0; j < 3; j++) { v[j] = &mesh.vertices[mesh.indices[3 * p + j]]; w[j] = &pos[(size_t)mesh.indices[3 * p + j] * 3]; }
         float* q = &b.tris[(size_t)sl * 12];
-        for (int j = 0; j < 3; j++) memcpy(q + 3 * j, v[j]->position, 12);          // object-space v0, v1, v2
+        for (int j = 0; j < 3; j++) memcpy(q + 3 * j, w[j], 12);                    // v0, v1, v2 (object space; world space when baked)
         memcpy(q + 9, &p, 4);                                                       // primitive index
         float* sh = &b.shade[(size_t)sl * 12];
         for (int j = 0; j < 3; j++) memcpy(sh + 3 * j, v[j]->normal, 12);
-        memcpy(sh + 10, &slot, 4);                                                  // mesh slot; the instance comes from the walk
+        memcpy(sh + 10, &mesh_slot, 4);                                             // mesh slot; the instance comes from the walk
         if (textured) {
             float* tx = &b.shade_tex[(size_t)sl * 24];
             for (int j = 0; j < 3; j++) { memcpy(tx + 2 * j, v[j]->base_color_tex_coord, 8); memcpy(tx + 6 + 2 * j, v[j]->normal_tex_coord, 8); }
@@ -623,8 +640,8 @@ int build_blas(SrScene* s, uint32_t slot) {
         const srh::BuildTri& t = tris[p];
         for (int a = 0; a < 3; a++) {                                               // the padded triangle box, as the builder bounds it
             const float pad = 4e-6f * (std::fabs(t.e1[a]) + std::fabs(t.e2[a]));
-            const float lo = std::min(v[0]->position[a], std::min(v[1]->position[a], v[2]->position[a])) - pad;
-            const float hi = std::max(v[0]->position[a], std::max(v[1]->position[a], v[2]->position[a])) + pad;
+            const float lo = std::min(w[0][a], std::min(w[1][a], w[2][a])) - pad;
+            const float hi = std::max(w[0][a], std::max(w[1][a], w[2][a])) + pad;
             b.lo[a] = std::min(b.lo[a], std::nextafter(lo, -INFINITY)); b.hi[a] = std::max(b.hi[a], std::nextafter(hi, INFINITY));
         }
     }
@@ -632,61 +649,40 @@ int build_blas(SrScene* s, uint32_t slot) {
     return SR_OK;
 }
 
-// Every live mesh's tree, triangle, shade and primitive -> slot records, one after the other, on the device.
-int upload_blases(SrScene* s) {
-    int rc;
-    const size_t nm = s->meshes.size();
-    s->blases.resize(nm);
-    s->blas_node_base.assign(nm, 0u); s->blas_tri_base.assign(nm, 0u);
-    uint64_t n_nodes = 0, n_tris = 0;
-    s->any_textured_tl = false; s->blas_stack = 0;
-    for (size_t m = 0; m < nm; m++) {
-        if (s->meshes[m].n_vertices == 0) continue;
-        if (!s->blases[m].valid && (rc = build_blas(s, (uint32_t)m)) != SR_OK) return rc;
-        s->blas_node_base[m] = (uint32_t)n_nodes; s->blas_tri_base[m] = (uint32_t)n_tris;
-        n_nodes += s->blases[m].n_nodes; n_tris += s->blases[m].n_tris;
-        s->any_textured_tl = s->any_textured_tl || !s->blases[m].shade_tex.empty();
-        s->blas_stack = std::max(s->blas_stack, s->blases[m].max_stack);
-    }
-    if (n_tris >= (1ull << 28) || n_nodes >= (1ull << 31)) return fail(SR_ERR_UNSUPPORTED, "the meshes together exceed 2^28 triangles (leaf reference encoding)");
-    std::vector<uint32_t> nodes((size_t)n_nodes * srl::kNodeDwords);
-    std::vector<float> tris((size_t)n_tris * 12), shade((size_t)n_tris * 12), shade_tex(s->any_textured_tl ? (size_t)n_tris * 24 : 0);
-    std::vector<uint32_t> slot_of_prim(n_tris ? n_tris : 1, 0u);
-    for (size_t m = 0; m < nm; m++) {
-        if (s->meshes[m].n_vertices == 0) continue;
-        const SrScene::HostBlas& b = s->blases[m];
-        const uint32_t nb = s->blas_node_base[m], tb = s->blas_tri_base[m];
+// Appends one tree with its triangle / shade / primitive -> slot records to the concatenated host arrays (references become global).
+struct BlasCat {
+    std::vector<uint32_t> nodes, slot_of_prim;
+    std::vector<float> tris, shade, shade_tex;
+    bool textured = false;
+    void append(const SrScene::HostBlas& b, uint32_t* node_base, uint32_t* tri_base) {
+        const uint32_t nb = (uint32_t)(nodes.size() / srl::kNodeDwords), tb = (uint32_t)(tris.size() / 12);
+        *node_base = nb; *tri_base = tb;
+        nodes.resize(nodes.size() + (size_t)b.n_nodes * srl::kNodeDwords);
         for (uint32_t i = 0; i < b.n_nodes; i++) {
             uint32_t* q = &nodes[((size_t)nb + i) * srl::kNodeDwords];
             memcpy(q, &b.nodes[(size_t)i * srl::kNodeDwords], srl::kNodeBytes);
-            for (int c = 0; c < srl::kBvhWidth; c++) {                               // references become global
+            for (int c = 0; c < srl::kBvhWidth; c++) {
                 const int ref = (int)q[srl::kChildOffset + c];
                 if (ref >= 0) q[srl::kChildOffset + c] = (uint32_t)(ref + (int)nb);
                 else { const uint32_t lv = ~(uint32_t)ref; const uint32_t cnt = lv & 7u; if (cnt) q[srl::kChildOffset + c] = ~((((lv >> 3) + tb) << 3) | cnt); }
             }
         }
-        if (b.n_tris) {
-            memcpy(&tris[(size_t)tb * 12], b.tris.data(), (size_t)b.n_tris * 48);
-            memcpy(&shade[(size_t)tb * 12], b.shade.data(), (size_t)b.n_tris * 48);
-            if (!b.shade_tex.empty()) memcpy(&shade_tex[(size_t)tb * 24], b.shade_tex.data(), (size_t)b.n_tris * 96);
-            for (uint32_t p = 0; p < b.n_tris; p++) slot_of_prim[(size_t)tb + p] = tb + b.slot_of_prim[p];
+        tris.insert(tris.end(), b.tris.begin(), b.tris.end());
+        shade.insert(shade.end(), b.shade.begin(), b.shade.end());
+        if (textured) {
+            shade_tex.resize((size_t)tb * 24, 0.0f);
+            if (!b.shade_tex.empty()) shade_tex.insert(shade_tex.end(), b.shade_tex.begin(), b.shade_tex.end());
+            else shade_tex.resize(((size_t)tb + b.n_tris) * 24, 0.0f);
         }
+        for (uint32_t p = 0; p < b.n_tris; p++) slot_of_prim.push_back(tb + b.slot_of_prim[p]);
     }
-    HIP_TRY(hipDeviceSynchronize());
-    if ((rc = s->d_blas_nodes.upload(nodes.data(), nodes.size() * 4)) != SR_OK) return rc;
-    if ((rc = s->d_tris.upload(tris.data(), tris.size() * 4)) != SR_OK) return rc;
-    if ((rc = s->d_shade.upload(shade.data(), shade.size() * 4)) != SR_OK) return rc;
-    if (s->any_textured_tl) { if ((rc = s->d_shade_tex.upload(shade_tex.data(), shade_tex.size() * 4)) != SR_OK) return rc; }
-    else s->d_shade_tex.release();
-    if ((rc = s->d_slot_of_gid.upload(slot_of_prim.data(), slot_of_prim.size() * 4)) != SR_OK) return rc;
-    s->blas_device_current = true;
-    return SR_OK;
-}
+};
 
 int two_level_build(SrScene* s) {
     const auto t0 = std::chrono::steady_clock::now();
     int rc;
-    if (!s->blas_device_current || !s->two_level) { if ((rc = upload_blases(s)) != SR_OK) return rc; }
+    const size_t nm = s->meshes.size();
+    s->blases.resize(nm);
     bool any_textured = false;
     if ((rc = upload_mesh_tables(s, &any_textured)) != SR_OK) return rc;
     // instance records + padded world-space boxes
@@ -694,31 +690,34 @@ int two_level_build(SrScene* s) {
     std::vector<srd::DevTlInstance> recs(ni ? ni : 1);
     memset(recs.data(), 0, recs.size() * sizeof(srd::DevTlInstance));
     std::vector<srh::BuildBox> boxes;
-    std::vector<uint32_t> box_inst;           // instances with a box (a singular transform collapses every triangle: no hit is possible)
+    std::vector<uint32_t> box_inst;
     boxes.reserve(ni); box_inst.reserve(ni);
+    std::vector<SrScene::HostBlas> baked;     // private world-space copies: instances whose transform cannot be inverted (well)
+    std::vector<uint32_t> baked_inst;
     const double eps = std::ldexp(1.0, -24);
+    uint32_t blas_stack = 0;
     for (size_t i = 0; i < ni; i++) {
         const srh::HostInstance& in = s->fid.instances[i];
-        const SrScene::HostBlas& b = s->blases[in.mesh_slot];
+        const srh::HostMesh& mesh = s->meshes[in.mesh_slot];
+        SrScene::HostBlas& b = s->blases[in.mesh_slot];
+        if (!b.valid) { b = SrScene::HostBlas(); if ((rc = build_blas(mesh, in.mesh_slot, nullptr, b)) != SR_OK) return rc; s->blas_device_current = false; }
         srd::DevTlInstance& r = recs[i];
         const float* M = in.o2w.m;
         memcpy(r.o2w, M, 48);
-        r.blas_root = s->blas_node_base[in.mesh_slot];
         r.tri_offset = in.tri_offset;
         r.mesh_slot = in.mesh_slot;
-        r.prim_base = s->blas_tri_base[in.mesh_slot];
+        if (b.n_tris == 0) continue;
         // inverse of the affine transform, in double
         const double a00 = M[0], a01 = M[1], a02 = M[2], a10 = M[4], a11 = M[5], a12 = M[6], a20 = M[8], a21 = M[9], a22 = M[10];
         const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
         const double det = a00 * c00 + a01 * c01 + a02 * c02;
-        if (b.n_tris == 0 || !(std::fabs(det) > 0.0) || !std::isfinite(1.0 / det)) continue;
         const double id = 1.0 / det;
         const double R[9] = {c00 * id, (a02 * a21 - a01 * a22) * id, (a01 * a12 - a02 * a11) * id,
                              c01 * id, (a00 * a22 - a02 * a20) * id, (a02 * a10 - a00 * a12) * id,
                              c02 * id, (a01 * a20 - a00 * a21) * id, (a00 * a11 - a01 * a10) * id};
         const double T[3] = {M[3], M[7], M[11]};
         double r_norm = 0.0, m_norm = 0.0, t_max = 0.0;
-        bool finite = true;
+        bool finite = std::isfinite(id) && det != 0.0;
         for (int row = 0; row < 3; row++) {
             for (int c = 0; c < 3; c++) r.w2o[4 * row + c] = (float)R[3 * row + c];
             r.w2o[4 * row + 3] = (float)(-(R[3 * row] * T[0] + R[3 * row + 1] * T[1] + R[3 * row + 2] * T[2]));
@@ -727,7 +726,27 @@ int two_level_build(SrScene* s) {
             t_max = std::max(t_max, std::fabs(T[row]));
             for (int c = 0; c < 4; c++) finite = finite && std::isfinite(r.w2o[4 * row + c]);
         }
-        if (!finite) continue;
+        // A transform of rank 2 still yields real (flat) world-space triangles, and a badly conditioned one stretches object space
+        // against world space: whatever the fp32 triangle test's own rounding moves a hit by in world space (on sliver triangles
+        // that is far more than a box's padding: the round-3 fuzzer found hits 8e-3 off their triangle) is multiplied by
+        // ||W2O|| on the way into the mesh's boxes. Such an instance gets a private world-space copy of its mesh's tree and is walked
+        // without a ray transform: there the boxes see exactly what the one-level form's boxes see.
+        if (!finite || !(r_norm * m_norm < kTlMaxCondition)) {
+            memset(r.w2o, 0, sizeof(r.w2o));
+            r.w2o[0] = r.w2o[5] = r.w2o[10] = 1.0f;
+            r.flags = 1u;
+            baked.emplace_back();
+            if ((rc = build_blas(mesh, in.mesh_slot, &in.o2w, baked.back())) != SR_OK) return rc;
+            baked_inst.push_back((uint32_t)i);
+            const SrScene::HostBlas& wb = baked.back();
+            bool box_ok = true;
+            srh::BuildBox bx;
+            for (int a = 0; a < 3; a++) { bx.lo[a] = wb.lo[a]; bx.hi[a] = wb.hi[a]; box_ok = box_ok && std::isfinite(bx.lo[a]) && std::isfinite(bx.hi[a]); }
+            blas_stack = std::max(blas_stack, wb.max_stack);
+            if (box_ok) { boxes.push_back(bx); box_inst.push_back((uint32_t)i); }
+            continue;
+        }
+        blas_stack = std::max(blas_stack, b.max_stack);
         // world box: the 8 corners of the mesh's (already padded) box, then padding for the rounding of the transformed vertices
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, p_max = 0.0;
         for (int corner = 0; corner < 8; corner++) {
@@ -748,6 +767,42 @@ int two_level_build(SrScene* s) {
         boxes.push_back(bx);
         box_inst.push_back((uint32_t)i);
     }
+    // every live mesh's records, one after the other (cached on the host per mesh), then the baked copies of this instance list
+    const bool had_baked = s->tl_baked;
+    if (!s->blas_device_current || !s->two_level || had_baked || !baked.empty()) {
+        BlasCat cat;
+        for (size_t m = 0; m < nm; m++) {
+            if (s->meshes[m].n_vertices == 0) continue;
+            if (!s->blases[m].valid) { s->blases[m] = SrScene::HostBlas(); if ((rc = build_blas(s->meshes[m], (uint32_t)m, nullptr, s->blases[m])) != SR_OK) return rc; }
+            cat.textured = cat.textured || !s->blases[m].shade_tex.empty();
+        }
+        s->blas_node_base.assign(nm, 0u); s->blas_tri_base.assign(nm, 0u);
+        for (size_t m = 0; m < nm; m++) if (s->meshes[m].n_vertices) cat.append(s->blases[m], &s->blas_node_base[m], &s->blas_tri_base[m]);
+        s->tl_baked_node_base.assign(baked.size(), 0u); s->tl_baked_tri_base.assign(baked.size(), 0u);
+        for (size_t k = 0; k < baked.size(); k++) cat.append(baked[k], &s->tl_baked_node_base[k], &s->tl_baked_tri_base[k]);
+        if (cat.tris.size() / 12 >= (1ull << 28) || cat.nodes.size() / srl::kNodeDwords >= (1ull << 31)) return fail(SR_ERR_UNSUPPORTED, "the meshes together exceed 2^28 triangles (leaf reference encoding)");
+        if (cat.textured) cat.shade_tex.resize(cat.tris.size() / 12 * 24, 0.0f);
+        if (cat.slot_of_prim.empty()) cat.slot_of_prim.push_back(0u);
+        HIP_TRY(hipDeviceSynchronize());
+        if ((rc = s->d_blas_nodes.upload(cat.nodes.data(), cat.nodes.size() * 4)) != SR_OK) return rc;
+        if ((rc = s->d_tris.upload(cat.tris.data(), cat.tris.size() * 4)) != SR_OK) return rc;
+        if ((rc = s->d_shade.upload(cat.shade.data(), cat.shade.size() * 4)) != SR_OK) return rc;
+        if (cat.textured) { if ((rc = s->d_shade_tex.upload(cat.shade_tex.data(), cat.shade_tex.size() * 4)) != SR_OK) return rc; }
+        else s->d_shade_tex.release();
+        if ((rc = s->d_slot_of_gid.upload(cat.slot_of_prim.data(), cat.slot_of_prim.size() * 4)) != SR_OK) return rc;
+        s->any_textured_tl = cat.textured;
+        s->tl_blas_nodes = cat.nodes.size() / srl::kNodeDwords; s->tl_blas_tris = cat.tris.size() / 12;
+        s->blas_device_current = true;
+        s->tl_baked = !baked.empty();
+    }
+    for (size_t i = 0; i < ni; i++) {
+        srd::DevTlInstance& r = recs[i];
+        if (r.flags & 1u) continue;
+        r.blas_root = s->blas_node_base[r.mesh_slot];
+        r.prim_base = s->blas_tri_base[r.mesh_slot];
+    }
+    for (size_t k = 0; k < baked.size(); k++) { recs[baked_inst[k]].blas_root = s->tl_baked_node_base[k]; recs[baked_inst[k]].prim_base = s->tl_baked_tri_base[k]; }
+    s->blas_stack = blas_stack;
     // the stack budget of the top-level tree is what the deepest mesh tree leaves of the walk's LDS stack
     const uint32_t left = kTlStackCap > s->blas_stack + srl::kLeafMax + 1u ? kTlStackCap - s->blas_stack - srl::kLeafMax - 1u : 0u;
     if (left < min_depth_for(boxes.size())) return fail(SR_ERR_UNSUPPORTED, "two-level structure: instance count and mesh size together need a deeper traversal stack than the kernels provide");
@@ -755,7 +810,7 @@ int two_level_build(SrScene* s) {
     srh::build_bvh_boxes(boxes, std::min(depth_for(boxes.size()), left), tl);
     std::vector<uint32_t> tl_inst(tl.order.size() ? tl.order.size() : 1, 0u);
     for (size_t k = 0; k < tl.order.size(); k++) tl_inst[k] = box_inst[tl.order[k]];
-    const uint32_t need = tl.max_stack + srl::kLeafMax + s->blas_stack + 1u;     // top-level entries + pending instances of a leaf + marker + mesh tree
+    const uint32_t need = tl.max_stack + srl::kLeafMax + s->blas_stack + 1u;     // top-level entries + pending instances of a leaf + mesh tree + 1
     if (need > kTlStackCap) return fail(SR_ERR_STATE, "two-level structure needs a deeper traversal stack than the kernels provide");
     HIP_TRY(hipDeviceSynchronize());
     if ((rc = upload_instance_tables(s)) != SR_OK) return rc;
@@ -772,12 +827,10 @@ int two_level_build(SrScene* s) {
     s->dev.slot_of_gid = (const uint32_t*)s->d_slot_of_gid.p;
     s->dev.counters = (unsigned long long*)s->d_misc.p;
     s->dev.n_tris = s->fid.n_triangles;
-    uint64_t blas_nodes = 0, blas_tris = 0;
-    for (size_t m = 0; m < s->meshes.size(); m++) if (s->meshes[m].n_vertices) { blas_nodes += s->blases[m].n_nodes; blas_tris += s->blases[m].n_tris; }
     s->stats.n_triangles = s->fid.n_triangles;
-    s->stats.n_nodes = tl.n_nodes + blas_nodes;
+    s->stats.n_nodes = tl.n_nodes + s->tl_blas_nodes;
     s->stats.node_bytes = s->stats.n_nodes * srl::kNodeBytes;
-    s->stats.tri_bytes = blas_tris * 48;
+    s->stats.tri_bytes = s->tl_blas_tris * 48;
     s->stats.max_depth = tl.max_depth;
     s->stats.max_stack = need;
     s->stack_entries = (int)((std::max(need, 3u) + 1u + 3u) & ~3u);

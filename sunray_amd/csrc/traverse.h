@@ -113,7 +113,9 @@ struct DevTlInstance {   // 128 B
                           // the ray transform and of the world-space vertices against the object-space boxes
     uint32_t mesh_slot;
     uint32_t prim_base;   // of the mesh's primitive -> slot table in slot_of_gid
-    uint32_t _pad[2];
+    uint32_t flags;       // bit 0: "baked" — the instance owns a WORLD-space copy of its mesh's tree and triangles (a transform that
+                          // cannot be inverted, e.g. a zero scale: its triangles are still real): no ray transform, no vertex transform
+    uint32_t _pad;
 };
 
 struct TravStats { uint32_t boxes, tris; };
@@ -204,9 +206,9 @@ SRD int pick(int4 c, uint32_t i) {   // two levels of selects (v_cndmask), no br
 // operations that flatten them in the one-level form — and tested against the world-space ray, so a hit carries exactly the bits
 // of the one-level form; the tie rule (smallest t, then lowest global triangle index = instance-major) is unchanged. Culling
 // stays conservative through the per-instance padding (DevTlInstance::pad_*). A lane's stack holds top-level entries below
-// index `lsp` and the current instance's entries from there; the instance is left when the stack falls back to `lsp` — after
-// the lane's postponed leaf, which belongs to it, has been tested. Work stealing hands over the bottom entry as before: a
-// top-level one with the world-space ray, or — once the donor has none left — one of the instance with its object-space ray.
+// index `lsp` and the current instance's entries from there; the instance is left when the stack falls back to `lsp`; a
+// postponed leaf remembers its own instance. Work stealing hands over the bottom entry as before: a top-level one with the
+// world-space ray, or — once the donor has none left — one of the instance with its object-space ray.
 // ---------------------------------------------------------------------------------------------
 constexpr int kWsRows = 7, kWsRowsTl = 8;
 SRD uint32_t ord_f32(float f) { const uint32_t b = __float_as_uint(f + 0.0f); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
@@ -248,22 +250,16 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
     int sp = 0, sb = 0, leaf = 0;
     int node = want ? 0 : kSentinel;
     // two-level state (compiled out of the one-level form)
-    bool in_blas = false, pending_leave = false;
+    bool in_blas = false;
     int lsp = 0;                         // first stack index of the current instance's entries
-    uint32_t inst = 0u;
+    uint32_t inst = 0u, leaf_inst = 0u;  // instance being walked; instance of the postponed leaf (the lane may have moved on meanwhile)
     f3 ro = o;                           // origin in the space being walked
     f3 winv = rs.inv;                    // 1/d of the world-space ray, to come back to without dividing again
     f3 pad = splat(0.0f);                // box padding of the current instance times |1/d'| per axis
     auto leave = [&]() { in_blas = false; ro = o; rs.inv = winv; pad = splat(0.0f); };
-    // Next entry of this lane's stack. Two-level: an instance is left when its entries are used up — but not before the lane's
-    // postponed leaf, which belongs to that instance, went through the triangle phase (the lane waits with node == kSentinel).
+    // Next entry of this lane's stack. Two-level: an instance is left when its entries are used up.
     auto pop = [&]() -> int {
-        if (TL) {
-            if (in_blas && sp == lsp) {
-                if (leaf != 0) { pending_leave = true; return kSentinel; }
-                leave();
-            }
-        }
+        if (TL) { if (in_blas && sp == lsp) leave(); }
         return sp == sb ? kSentinel : stack_base[(--sp) * stride];
     };
     for (;;) {
@@ -320,8 +316,8 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                         best_t = tmax; best_gid = 0xFFFFFFFFu;
                         sp = 0; sb = 0;
                         if (TL) {
-                            winv = d_winv; lsp = 0; pending_leave = false;
-                            in_blas = d_blas; inst = d_inst;
+                            winv = d_winv; lsp = 0;
+                            in_blas = d_blas; inst = d_inst; leaf_inst = d_inst;
                             if (d_blas) { ro = d_ro; pad = d_pad; }
                             else { ro = o; rs.inv = d_winv; pad = splat(0.0f); }
                         }
@@ -341,12 +337,14 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                     inst = sc.tl_inst[first];
                     const float4* q = reinterpret_cast<const float4*>(sc.tl_instances + inst);
                     const float4 r0 = q[0], r1 = q[1], r2 = q[2], m6 = q[6];
-                    ro = mk3(((r0.x * o.x + r0.y * o.y) + r0.z * o.z) + r0.w, ((r1.x * o.x + r1.y * o.y) + r1.z * o.z) + r1.w,
-                             ((r2.x * o.x + r2.y * o.y) + r2.z * o.z) + r2.w);
-                    const f3 rd = mk3((r0.x * d.x + r0.y * d.y) + r0.z * d.z, (r1.x * d.x + r1.y * d.y) + r1.z * d.z, (r2.x * d.x + r2.y * d.y) + r2.z * d.z);
-                    rs = ray_setup(ro, rd);
-                    const float pd = fmaf(m6.z, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)), m6.w);
-                    pad = mk3(pd * fabsf(rs.inv.x), pd * fabsf(rs.inv.y), pd * fabsf(rs.inv.z));
+                    if ((__float_as_uint(q[7].z) & 1u) == 0u) {
+                        ro = mk3(((r0.x * o.x + r0.y * o.y) + r0.z * o.z) + r0.w, ((r1.x * o.x + r1.y * o.y) + r1.z * o.z) + r1.w,
+                                 ((r2.x * o.x + r2.y * o.y) + r2.z * o.z) + r2.w);
+                        const f3 rd = mk3((r0.x * d.x + r0.y * d.y) + r0.z * d.z, (r1.x * d.x + r1.y * d.y) + r1.z * d.z, (r2.x * d.x + r2.y * d.y) + r2.z * d.z);
+                        rs = ray_setup(ro, rd);
+                        const float pd = fmaf(m6.z, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)), m6.w);
+                        pad = mk3(pd * fabsf(rs.inv.x), pd * fabsf(rs.inv.y), pd * fabsf(rs.inv.z));
+                    }   // a baked instance's tree is in world space: the ray stays as it is (ro == o, rs.inv == winv, pad == 0 here)
                     lsp = sp;
                     in_blas = true;
                     node = (int)__float_as_uint(m6.x);
@@ -374,10 +372,13 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                     p.az = __uint_as_float(((ex >> 16) & 0xFFu) << 23) * rs.inv.z;
                     const float bx = (h0.x - ro.x) * rs.inv.x, by = (h0.y - ro.y) * rs.inv.y, bz = (h0.z - ro.z) * rs.inv.z;
                     p.bnx = bx - pad.x; p.bfx = bx + pad.x; p.bny = by - pad.y; p.bfy = by + pad.y; p.bnz = bz - pad.z; p.bfz = bz + pad.z;
-                    b0 = child_hit_tl<0>(p, t_lo, cull, n0);
-                    b1 = child_hit_tl<1>(p, t_lo, cull, n1);
-                    b2 = child_hit_tl<2>(p, t_lo, cull, n2);
-                    b3 = child_hit_tl<3>(p, t_lo, cull, n3);
+                    // An unused child decodes to an inverted box, which nothing can hit — unless the padding exceeds the node's own
+                    // extent (an ill-conditioned instance): its reference (-1) is checked as well, or such children would be pushed and
+                    // the stack outgrow what the builders sized it for.
+                    b0 = child_hit_tl<0>(p, t_lo, cull, n0) && child.x != -1;
+                    b1 = child_hit_tl<1>(p, t_lo, cull, n1) && child.y != -1;
+                    b2 = child_hit_tl<2>(p, t_lo, cull, n2) && child.z != -1;
+                    b3 = child_hit_tl<3>(p, t_lo, cull, n3) && child.w != -1;
                 } else {
                     NodePlanes p;
                     p.nx = sgx ? HX : LX; p.fx = sgx ? LX : HX;
@@ -417,19 +418,15 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                 stack_base[sp * stride] = child.z; sp += (b2 && k2 != kmin) ? 1 : 0;
                 stack_base[sp * stride] = child.w; sp += (b3 && k3 != kmin) ? 1 : 0;
                 node = (kmin != 0xFFFFFFFFu) ? pick(child, slot) : pop();
-                if (node < 0 && node != kSentinel && leaf == 0 && (!TL || in_blas)) { leaf = node; node = pop(); }
+                if (node < 0 && node != kSentinel && leaf == 0 && (!TL || in_blas)) { leaf = node; leaf_inst = inst; node = pop(); }
             }
         }
         while (leaf != 0) {
             const uint32_t lv = ~(uint32_t)leaf;
             const uint32_t slot = lv >> 3, cnt = lv & 7u;
             leaf = cnt > 1u ? (int)~(((slot + 1u) << 3) | (cnt - 1u)) : 0;
-            // (two-level: `inst` is still the leaf's instance — the lane cannot have left it with the leaf pending)
-            const uint32_t leaf_inst = inst;
-            if (leaf == 0) {
-                if (TL && pending_leave) { pending_leave = false; leave(); node = pop(); }
-                else if (node < 0 && (!TL || in_blas)) { leaf = node; node = pop(); }
-            }
+            const uint32_t cur_inst = leaf_inst;          // instance of THIS triangle (the chaining below may move on to another leaf)
+            if (leaf == 0 && node < 0 && (!TL || in_blas)) { leaf = node; leaf_inst = inst; node = pop(); }
             if (cnt == 0u) continue;
             const float4 t0 = tris[(size_t)slot * 3 + 0];
             const float4 t1 = tris[(size_t)slot * 3 + 1];
@@ -441,23 +438,25 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
             if (TL) {
                 // object-space v0, v1, v2 -> world space with transform_point (rt_utils.slang:278-281), exactly as the one-level form
                 // flattens a triangle; the test itself runs on the world-space ray
-                const float4* q = reinterpret_cast<const float4*>(sc.tl_instances + leaf_inst);
+                const float4* q = reinterpret_cast<const float4*>(sc.tl_instances + cur_inst);
                 const float4 m0 = q[3], m1 = q[4], m2 = q[5];
+                const bool baked = (__float_as_uint(q[7].z) & 1u) != 0u;                     // its records already hold world-space vertices
                 const f3 a = mk3(t0.x, t0.y, t0.z), b = mk3(t0.w, t1.x, t1.y), c = mk3(t1.z, t1.w, t2.x);
-                const f3 wa = mk3(((m0.x * a.x + m0.y * a.y) + m0.z * a.z) + m0.w * 1.0f, ((m1.x * a.x + m1.y * a.y) + m1.z * a.z) + m1.w * 1.0f,
+                f3 wa = mk3(((m0.x * a.x + m0.y * a.y) + m0.z * a.z) + m0.w * 1.0f, ((m1.x * a.x + m1.y * a.y) + m1.z * a.z) + m1.w * 1.0f,
                                   ((m2.x * a.x + m2.y * a.y) + m2.z * a.z) + m2.w * 1.0f);
-                const f3 wb = mk3(((m0.x * b.x + m0.y * b.y) + m0.z * b.z) + m0.w * 1.0f, ((m1.x * b.x + m1.y * b.y) + m1.z * b.z) + m1.w * 1.0f,
-                                  ((m2.x * b.x + m2.y * b.y) + m2.z * b.z) + m2.w * 1.0f);
-                const f3 wc = mk3(((m0.x * c.x + m0.y * c.y) + m0.z * c.z) + m0.w * 1.0f, ((m1.x * c.x + m1.y * c.y) + m1.z * c.z) + m1.w * 1.0f,
-                                  ((m2.x * c.x + m2.y * c.y) + m2.z * c.z) + m2.w * 1.0f);
+                f3 wb = mk3(((m0.x * b.x + m0.y * b.y) + m0.z * b.z) + m0.w * 1.0f, ((m1.x * b.x + m1.y * b.y) + m1.z * b.z) + m1.w * 1.0f,
+                            ((m2.x * b.x + m2.y * b.y) + m2.z * b.z) + m2.w * 1.0f);
+                f3 wc = mk3(((m0.x * c.x + m0.y * c.y) + m0.z * c.z) + m0.w * 1.0f, ((m1.x * c.x + m1.y * c.y) + m1.z * c.z) + m1.w * 1.0f,
+                            ((m2.x * c.x + m2.y * c.y) + m2.z * c.z) + m2.w * 1.0f);
+                if (baked) { wa = a; wb = b; wc = c; }
                 is_hit = intersect_tri(o, d, wa, wb - wa, wc - wa, tmin, tmax, t, u, v);
-                gid = sc.tl_instances[leaf_inst].tri_offset + __float_as_uint(t2.y);
+                gid = sc.tl_instances[cur_inst].tri_offset + __float_as_uint(t2.y);
             } else {
                 is_hit = intersect_tri(o, d, mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), tmin, tmax, t, u, v);
                 gid = __float_as_uint(t2.y);
             }
             if (is_hit) {
-                if (ANY) { keys[root] = 0ull; node = kSentinel; sp = sb; leaf = 0; if (TL) { in_blas = false; pending_leave = false; } break; }
+                if (ANY) { keys[root] = 0ull; node = kSentinel; sp = sb; leaf = 0; if (TL) { in_blas = false; } break; }
                 if (t < best_t || (t == best_t && gid < best_gid)) {
                     best_t = t; best_gid = gid;
                     cull = fminf(cull, fmaf(fabsf(t), 1e-5f, t));
@@ -466,7 +465,7 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                     if (keys[root] == key) {   // this lane holds the minimum: its payload stands
                         pay[0 * stride + root] = __float_as_int(t); pay[1 * stride + root] = __float_as_int(u);
                         pay[2 * stride + root] = __float_as_int(v); pay[3 * stride + root] = (int)slot;
-                        if (TL) pay[4 * stride + root] = (int)leaf_inst;
+                        if (TL) pay[4 * stride + root] = (int)cur_inst;
                     }
                 }
             }

@@ -224,3 +224,25 @@ def test_two_level_renderer_and_instrumented_variants(rt, oracle, monkeypatch):
         assert (c.boxes_tested > 0 and c.tris_tested > 0) == instrumented
     assert plain[0][:2] == plain[1][:2]
     assert_bits_equal(plain[0][2], plain[1][2], "instrumented two-level variant")
+
+
+def test_two_level_empty_scene_and_singular_instances(rt, oracle, blue_noise):
+    """No instances at all (a top-level tree of nothing), and instances whose transform is singular (a zero scale: every triangle
+    collapses in world space and cannot be hit in either form; the two-level form gives such an instance no box) next to regular ones."""
+    W, H = 64, 40
+    sc = rt.Scene(0, instancing="two_level")
+    sc.set_instances([])
+    assert sc.two_level() and sc.bvh_stats().n_triangles == 0
+    fr = rt.DeviceFrame(W, H, blue_noise)
+    m = rt.camera_matrices((0, 1, 3), (0, 1, 0), 45.0, W, H)
+    sc.trace_ris(fr, m, 0); sc.trace_final(fr, m, 0)
+    h = fr.host()
+    assert not h["raw_color"][:, :3].any() and (h["depth"] == 0x7c00).all()          # sky everywhere
+    rays = random_rays(500, 2)
+    assert (rt.hits_from_device(sc.trace_closest(rt.rays_to_device(rays), len(rays)))["t"] == -1.0).all()
+    desc = scenes.cornell_glass_mirror()
+    flat = np.array([1, 0, 0, 0.2, 0, 0, 0, 1.0, 0, 0, 1, 0.1], dtype=np.float32)      # y scale 0: a sphere squashed into a disc of zero-area triangles
+    zero = np.zeros(12, dtype=np.float32)
+    key_sphere = desc.meshes[-1].key
+    desc.instances = [(k, list(xs) + ([flat, zero] if k == key_sphere else [])) for k, xs in desc.instances]
+    frames_equal_oracle(rt, oracle, desc, 96, 64, 2, blue_noise)
