@@ -237,6 +237,7 @@ def main():
     st = scene.bvh_stats()
     frame = rt.DeviceFrame(W, H, blue_noise, device=device)
     cfg = abi.SrTraceConfig.reference()
+    cfg.flags |= int(os.environ.get("SUNRAY_BENCH_TRACE_FLAGS", "0"), 0)   # experiments only (e.g. 1 = no ray counting); the default run sets none
     import copy
     axis = os.environ.get("SUNRAY_BENCH_AXIS", "cols")          # column strips (default) or "rows"
     bounds = None
@@ -368,7 +369,7 @@ def main():
 
     red_dev = "cpu" if rehearsal else device
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    rays = torch.tensor([float(c.closest_queries + c.any_queries), float(c.closest_queries), float(c.any_queries), float(c.reused_primary_hits)],
+    rays = torch.tensor([float(c.closest_queries + c.any_queries), float(c.closest_queries), float(c.any_queries), float(c.reused_primary_hits + c.reused_visibility_queries)],
                         dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
@@ -470,7 +471,8 @@ def main():
                 "closest_per_frame": total_closest / args.steps,
                 "any_per_frame": total_any / args.steps,
                 # the reference issues every pixel's camera-ray TraceRay twice (ray_gen_ris.slang:75, ray_gen_final.slang:80); with the
-                # primary-hit hand-off the final pass reads the RIS pass's payload instead. `value` counts traversals executed only.
+                # primary-hit hand-off the final pass reads the RIS pass's payload instead, and its final GI visibility query is not traced
+                # again where it repeats a neighbour's (SrRayCounters.reused_*). `value` counts traversals executed only.
                 "traced_queries_per_frame": total_rays / args.steps,
                 "reference_queries_per_frame": (total_rays + total_reused) / args.steps,
                 "primary_hit_hand_off": bool(reuse),

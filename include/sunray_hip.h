@@ -182,7 +182,9 @@ typedef struct SrHit {
 } SrHit;
 
 /* Compile-time constants of the reference exposed as knobs (SURVEY.md §5 "Config / flags").
- * sr_trace_config_default() fills the reference values. */
+ * sr_trace_config_default() fills the reference values. max_bounces and virtual_bounces above
+ * SR_MAX_BOUNCES are refused (SR_ERR_INVALID_ARG): the passes count a pixel's queries in packed fields. */
+#define SR_MAX_BOUNCES 8192u
 typedef struct SrTraceConfig {
     uint32_t max_bounces;     /* BOUNCES = 10            ray_gen_final.slang:41  */
     uint32_t shadow_bounces;  /* SHADOW_BOUNCES = 5      ray_gen_final.slang:42  */
@@ -203,6 +205,9 @@ typedef struct SrTraceConfig {
  * for its neighbours' spatial reuse in tile-parallel rendering, so that counted rays are
  * exactly the rays of the equivalent single-GPU frame. */
 #define SR_TRACE_FLAG_UNCOUNTED 1u
+/* Trace every query the reference issues, also where its answer is known from an identical query of the same pixel in the same
+ * pass (SrRayCounters.reused_visibility_queries stays 0). Same results either way; for accounting and A/B. */
+#define SR_TRACE_FLAG_TRACE_EVERY_QUERY 2u
 
 typedef struct SrScene SrScene; /* opaque: mesh tables + instance tables + BVH ("TLAS") on one GPU */
 
@@ -261,6 +266,10 @@ typedef struct SrRayCounters {
     uint64_t reused_primary_hits; /* TraceRay(RAY_FLAG_NONE) calls of the reference's final pass answered from
                                      SrRtParams.primary_payload without a traversal: the reference issues
                                      closest_queries + reused_primary_hits closest-hit queries */
+    uint64_t reused_visibility_queries; /* TraceRay(ACCEPT_FIRST_HIT) calls of the reference's final pass answered without a traversal:
+                                     ray_gen_final.slang:304-316 when the combined GI reservoir's sample is a spatial neighbour's, whose
+                                     identical ray (:276-286) was found unoccluded a moment before. The reference issues
+                                     any_queries + reused_visibility_queries existence queries */
 } SrRayCounters;
 
 /* ------------------------------------------------------------------------------------------ */

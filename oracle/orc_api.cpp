@@ -82,6 +82,7 @@ void orc_reset_counters(void* sp) { ((Scene*)sp)->counters = Counters{}; }
 void orc_read_counters(void* sp, SrRayCounters* out) {
     const Counters& c = ((Scene*)sp)->counters;
     out->closest_queries = c.closest; out->any_queries = c.any; out->boxes_tested = c.boxes; out->tris_tested = c.tris;
+    out->reused_visibility_queries = 0;
     out->reused_primary_hits = 0;   // the oracle issues every TraceRay of the reference: SrRtParams.primary_payload is ignored here
 }
 

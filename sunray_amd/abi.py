@@ -9,6 +9,8 @@ import numpy as np
 
 NULL_TEXTURE = 0xFFFFFFFF
 TRACE_FLAG_UNCOUNTED = 1
+TRACE_FLAG_TRACE_EVERY_QUERY = 2
+MAX_BOUNCES = 8192          # SR_MAX_BOUNCES
 
 # T1 VertexAttributes (rt_types.slang:24-36) — 96 B
 VERTEX = np.dtype([
@@ -96,7 +98,7 @@ def post_params(frame, frame_count, ptr, exposure=1.0, denoise_passes=4):
 
 class SrRayCounters(C.Structure):
     _fields_ = [("closest_queries", C.c_uint64), ("any_queries", C.c_uint64),
-                ("boxes_tested", C.c_uint64), ("tris_tested", C.c_uint64), ("reused_primary_hits", C.c_uint64)]
+                ("boxes_tested", C.c_uint64), ("tris_tested", C.c_uint64), ("reused_primary_hits", C.c_uint64), ("reused_visibility_queries", C.c_uint64)]
 
 
 class SrBvhStats(C.Structure):

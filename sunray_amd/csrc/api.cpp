@@ -103,8 +103,7 @@ struct DeviceBuffer {
 
 }  // namespace
 
-constexpr size_t kQueueHeadOffset = 256;   // d_misc: [0,40) ray counters, [256, 256 + 16 * kQueueHeads) queue heads
-constexpr uint32_t kQueueHeads = 64;
+constexpr size_t kCounterBytes = (size_t)srd::kCounterSlots * srd::kCounterStride * 8;   // the copies of the ray counters (traverse.h)
 
 struct SrScene {
     int device = 0;
@@ -152,7 +151,6 @@ struct SrScene {
     struct TileSchedule { int which = -1; uint32_t width = 0 /* columns of the launch rectangle */, y0 = 0, y1 = 0, x0 = 0; DeviceBuffer cost, order; bool have_order = false; uint64_t last_use = 0; uint32_t uses = 0; };
     std::vector<TileSchedule> schedules;
     uint64_t schedule_clock = 0;
-    uint32_t queue_head_clock = 0;          // next entry of the queue-head ring (trace_queue)
     int tile_scheduling = 1;                // SR_TILE_SCHEDULING=0 in the environment disables it (A/B)
     int fast_build_ploc = 16;               // device fast build: PLOC with this search radius (default), 0 = radix tree (SR_FAST_BUILD=lbvh | ploc<r>)
     uint32_t forced_op = SR_OP_NONE;        // sr_scene_force_next_op (test / bench hook)
@@ -261,8 +259,8 @@ int sr_scene_create(int device, SrScene** out) {
     if (const char* ev = getenv("SR_FAST_BUILD")) s->fast_build_ploc = !strcmp(ev, "lbvh") ? 0 : (!strncmp(ev, "ploc", 4) && atoi(ev + 4) > 0 ? atoi(ev + 4) : 16);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
-    // counters (4 x u64), diagnostics and the ring of queue heads, in one small allocation of their own
-    const std::vector<unsigned char> zeros(kQueueHeadOffset + 16 * kQueueHeads, 0);
+    // the copies of the ray counters, in one small allocation of their own
+    const std::vector<unsigned char> zeros(kCounterBytes, 0);
     int rc = s->d_misc.upload(zeros.data(), zeros.size());
     if (rc != SR_OK) { delete s; return rc; }
     *out = s;
@@ -1162,31 +1160,25 @@ int sr_scene_resolve_triangle(const SrScene* s, uint32_t tri, uint32_t* instance
     return SR_OK;
 }
 
-static int trace_queue(SrScene* s, const SrRay* rays, uint32_t n, SrHit* hits, uint32_t* occluded, int any, void* stream) {
+static int trace_list(SrScene* s, const SrRay* rays, uint32_t n, SrHit* hits, uint32_t* occluded, int any, void* stream) {
     if (!s) return fail(SR_ERR_INVALID_ARG, "sr_trace: scene is null");
     if (!s->built) return fail(SR_ERR_STATE, "sr_trace: call sr_scene_set_instances first (TLAS not built)");
     if (n && (!rays || (any ? (void*)occluded : (void*)hits) == nullptr)) return fail(SR_ERR_INVALID_ARG, "sr_trace: null ray/output pointer");
     int rc = bind_device(s);
     if (rc != SR_OK) return rc;
-    if (n > (1u << 31)) return fail(SR_ERR_UNSUPPORTED, "sr_trace: more than 2^31 rays in one call (the queue head is a 32-bit counter)");
+    if (n > (1u << 31)) return fail(SR_ERR_UNSUPPORTED, "sr_trace: more than 2^31 rays in one call (ray indices are 32-bit)");
     hipStream_t st = (hipStream_t)stream;
-    // every launch gets a queue head of its own from a small ring, so launches on different streams never share one
-    uint32_t* queue_head = (uint32_t*)((char*)s->d_misc.p + kQueueHeadOffset + 16 * (s->queue_head_clock++ % kQueueHeads));
-    const int lds_per_block = srk_lds_rows(s->stack_entries, s->two_level ? 1 : 0) * 256 * 4;
-    int per_cu = std::max(1, std::min(8, 160 * 1024 / lds_per_block));  // persistent grid = LDS-limited residency
-    if (const char* e = getenv("SR_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));   // tuning switch
-    const int n_blocks = s->n_cus * per_cu;
     ScopedTiming tm(s, any ? kAny : kClosest, st);
-    int e = srk_launch_trace(s->dev, rays, n, hits, occluded, queue_head, any, s->instrumented, s->two_level ? 1 : 0, n_blocks, s->stack_entries, st);
+    int e = srk_launch_trace(s->dev, rays, n, hits, occluded, any, s->instrumented, s->two_level ? 1 : 0, s->stack_entries, st);
     if (e != 0) return fail(SR_ERR_HIP, std::string("trace kernel launch: ") + hipGetErrorString((hipError_t)e));
     return SR_OK;
 }
 
 int sr_trace_closest(const SrScene* s, const SrRay* rays, uint32_t n, SrHit* hits, void* stream) {
-    return trace_queue(const_cast<SrScene*>(s), rays, n, hits, nullptr, 0, stream);
+    return trace_list(const_cast<SrScene*>(s), rays, n, hits, nullptr, 0, stream);
 }
 int sr_trace_any(const SrScene* s, const SrRay* rays, uint32_t n, uint32_t* occluded, void* stream) {
-    return trace_queue(const_cast<SrScene*>(s), rays, n, nullptr, occluded, 1, stream);
+    return trace_list(const_cast<SrScene*>(s), rays, n, nullptr, occluded, 1, stream);
 }
 
 int sr_shade_closest_hit(const SrScene* s, const SrHit* hits, uint32_t n, SrRayPayload* payloads, void* stream) {
@@ -1231,6 +1223,8 @@ static int run_pass(const SrRtParams* p, int which, void* stream) {
             return fail(SR_ERR_INVALID_ARG, std::string(name) + ": blue-noise texture missing");
     }
     if ((uint64_t)p->width * p->height >= (1ull << 31)) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": extent too large");
+    if (p->config.max_bounces > SR_MAX_BOUNCES || p->config.virtual_bounces > SR_MAX_BOUNCES)
+        return fail(SR_ERR_INVALID_ARG, std::string(name) + ": max_bounces / virtual_bounces above SR_MAX_BOUNCES");
     uint32_t y0 = 0, y1 = p->height;
     if (p->tile_h) {
         if (p->tile_y0 >= p->height) return fail(SR_ERR_INVALID_ARG, std::string(name) + ": tile outside the image");
@@ -1382,7 +1376,7 @@ int sr_scene_reset_counters(SrScene* s, void* stream) {
     if (!s) return fail(SR_ERR_INVALID_ARG, "sr_scene_reset_counters: scene is null");
     int rc = bind_device(s);
     if (rc != SR_OK) return rc;
-    HIP_TRY(hipMemsetAsync(s->d_misc.p, 0, 40, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(s->d_misc.p, 0, kCounterBytes, (hipStream_t)stream));
     return SR_OK;
 }
 
@@ -1390,10 +1384,13 @@ int sr_scene_read_counters(SrScene* s, void* stream, SrRayCounters* out) {
     if (!s || !out) return fail(SR_ERR_INVALID_ARG, "sr_scene_read_counters: null argument");
     int rc = bind_device(s);
     if (rc != SR_OK) return rc;
-    unsigned long long v[5];
+    std::vector<unsigned long long> copies(kCounterBytes / 8);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    HIP_TRY(hipMemcpy(v, s->d_misc.p, sizeof(v), hipMemcpyDeviceToHost));
-    out->closest_queries = v[0]; out->any_queries = v[1]; out->boxes_tested = v[2]; out->tris_tested = v[3]; out->reused_primary_hits = v[4];
+    HIP_TRY(hipMemcpy(copies.data(), s->d_misc.p, kCounterBytes, hipMemcpyDeviceToHost));
+    unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t slot = 0; slot < srd::kCounterSlots; slot++)
+        for (int k = 0; k < 6; k++) v[k] += copies[(size_t)slot * srd::kCounterStride + k];
+    out->closest_queries = v[0]; out->any_queries = v[1]; out->boxes_tested = v[2]; out->tris_tested = v[3]; out->reused_primary_hits = v[4]; out->reused_visibility_queries = v[5];
     return SR_OK;
 }
 

@@ -39,7 +39,7 @@ struct PassArgs {
 }  // namespace srd
 
 int srk_launch_trace(const srd::DevScene& sc, const SrRay* rays, uint32_t n, SrHit* hits, uint32_t* occluded,
-                     uint32_t* queue_head, int any, int stats, int two_level, int n_blocks, int stack_entries, hipStream_t stream);
+                     int any, int stats, int two_level, int stack_entries, hipStream_t stream);
 int srk_launch_shade(const srd::DevScene& sc, const SrHit* hits, uint32_t n, SrRayPayload* out, hipStream_t stream);
 int srk_launch_any_hit(const srd::DevScene& sc, const SrHit* hits, uint32_t n, uint32_t* ignored, hipStream_t stream);
 int srk_launch_pass(const srd::PassArgs& args, int which, int stats, int textured, int two_level, int stack_entries, hipStream_t stream);

@@ -1,12 +1,12 @@
 // HIP kernels of the ray-tracing hot path for gfx950 (MI355X).
 //
-//   trace_queue_kernel<ANY>                  — persistent-threads ray-queue tracers (K2 / K3)
+//   trace_rays_kernel<ANY>                   — ray-list tracers, one wave per 64 rays (K2 / K3)
 //   shade_closest_hit_kernel                 — closest_hit.slang / ray_miss.slang on hit records (K4/K6)
 //   any_hit_kernel                           — any_hit.slang's alpha test on hit records (K5; never part of a traversal)
 //   ris_kernel                               — ray_gen_ris.slang:12-440   (K1, K7, K8, K9)
 //   final_kernel                             — ray_gen_final.slang:11-436 (K1, K10)
 //
-// Launch geometry: the ray-queue and shade kernels use 256-thread workgroups; the two per-pixel passes use ONE WAVE per
+// Launch geometry: the ray-list and shade kernels use 256-thread workgroups; the two per-pixel passes use ONE WAVE per
 // workgroup, owning an 8x8 pixel tile (coherent primary rays per wave; a 4-wave workgroup would hold its LDS until its
 // slowest wave finished). Workgroups are dealt to screen tiles XCD-aware: blocks b and b+8 share an XCD (round-robin
 // dispatch), XCD x owns column band x of the image, so its private 4 MiB L2 holds the part of the BVH under that band;
@@ -20,40 +20,41 @@ constexpr int kBlock = 256;        // ray-queue and shade kernels
 constexpr int kPassBlock = 64;     // the two pass megakernels: one wave = one workgroup = one 8x8 pixel tile
 constexpr int kPassTile = 8;
 static int lds_extra_rows(int two_level) { return two_level ? kWsRowsTl : kWsRows; }   // LDS rows of the work-stealing traversal in front of the stack levels
-constexpr int kPassWaves = 4;      // __launch_bounds__ second argument on HIP: waves per SIMD (4 -> VGPR budget 128)
+#ifndef SR_PASS_WAVES
+#define SR_PASS_WAVES 4
+#endif
+constexpr int kPassWaves = SR_PASS_WAVES;      // __launch_bounds__ second argument on HIP: waves per SIMD (4 -> VGPR budget 128)
 
 // Wave-wide sum, then one atomic per wave (rays are counted, not estimated: SURVEY.md §8d).
-SRD void flush_counter(unsigned long long* dst, uint32_t v) {
+SRD void flush_counter(unsigned long long* counters, int which, uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, (unsigned long long)v);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(counters + (blockIdx.x & (kCounterSlots - 1u)) * kCounterStride + which, (unsigned long long)v);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Ray-queue tracers. Persistent threads: the grid is sized to the machine (blocks_per_cu * 256 CUs),
-// each wave pulls 64 rays at a time from a global queue head until the queue is empty.
+// Ray-list tracers: one wave per 64 consecutive rays, four waves to a workgroup, workgroups in list order; the hardware's workgroup
+// dispatcher is the load balancer. (Giving each XCD one contiguous eighth of the list instead — neighbouring rays then share nodes in
+// one L2 — lost on every ray set tried: primary rays 0.36 ms against 0.24, the eighths differ too much in cost.)
+// (Rounds 1-2 ran a machine-sized grid pulling 64 rays per atomicAdd on a queue head: adds of all waves on one address complete one
+// every ~14 ns, which capped 2 M rays at 0.47 ms whatever the rays did — DESIGN.md section 5.)
 // ---------------------------------------------------------------------------------------------
 template <bool ANY, bool STATS, bool TL>
-__global__ __launch_bounds__(kBlock) void trace_queue_kernel(DevScene sc, const SrRay* __restrict__ rays, uint32_t n,
-                                                             SrHit* __restrict__ hits, uint32_t* __restrict__ occluded,
-                                                             uint32_t* __restrict__ queue_head) {
+__global__ __launch_bounds__(kBlock) void trace_rays_kernel(DevScene sc, const SrRay* __restrict__ rays, uint32_t n,
+                                                            SrHit* __restrict__ hits, uint32_t* __restrict__ occluded) {
     extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kBlock], sized at launch
     const int lane = threadIdx.x & 63;
     int* stack = s_stack + threadIdx.x;
     uint32_t n_queries = 0;
     TravStats st; st.boxes = 0; st.tris = 0;
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(queue_head, 64u);
-        base = __shfl(base, 0);
-        if (base >= n) break;  // wave-uniform exit: every wave reaches it once the queue is drained
+    const uint32_t base = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64u;
+    if (base < n) {                                                 // wave-uniform
         const uint32_t i = base + lane;
-        {
-            const uint32_t ic = i < n ? i : n - 1u;
-            const float4 ra = reinterpret_cast<const float4*>(rays)[ic * 2 + 0];
-            const float4 rb = reinterpret_cast<const float4*>(rays)[ic * 2 + 1];
-            TravHit h;
-            const bool found = traverse_ws<ANY, STATS, TL>(sc, i < n, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), ra.w, rb.w, h, stack, kBlock, st);
-            if (i < n) {
+        const uint32_t ic = i < n ? i : n - 1u;
+        const float4 ra = reinterpret_cast<const float4*>(rays)[(size_t)ic * 2 + 0];
+        const float4 rb = reinterpret_cast<const float4*>(rays)[(size_t)ic * 2 + 1];
+        TravHit h;
+        const bool found = traverse_ws<ANY, STATS, TL>(sc, i < n, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), ra.w, rb.w, h, stack, kBlock, st);
+        if (i < n) {
             n_queries++;
             if (ANY) occluded[i] = found ? 1u : 0u;
             else {
@@ -61,11 +62,10 @@ __global__ __launch_bounds__(kBlock) void trace_queue_kernel(DevScene sc, const 
                 o.x = h.t; o.y = h.u; o.z = h.v; o.w = __uint_as_float(h.gid);
                 reinterpret_cast<float4*>(hits)[i] = o;
             }
-            }
         }
     }
-    flush_counter(sc.counters + (ANY ? 1 : 0), n_queries);
-    if (STATS) { flush_counter(sc.counters + 2, st.boxes); flush_counter(sc.counters + 3, st.tris); }
+    flush_counter(sc.counters, (ANY ? 1 : 0), n_queries);
+    if (STATS) { flush_counter(sc.counters, 2, st.boxes); flush_counter(sc.counters, 3, st.tris); }
 }
 
 __global__ __launch_bounds__(kBlock) void shade_closest_hit_kernel(DevScene sc, const SrHit* __restrict__ hits, uint32_t n,
@@ -118,10 +118,16 @@ SRD void primary_ray(const SrMatrices& m, uint32_t px, uint32_t py, uint32_t W, 
 struct PixelCtx {
     const PassArgs& a;
     int* stack;
-    uint32_t n_closest, n_any;
+    // Query counts of the lane's pixel in ONE register (the passes sit at their register budget; a register per counter showed up as
+    // 20 % of final_kernel): bits 0-15 existence queries, 16-30 closest-hit queries, bit 31 = the one existence query of the
+    // reference that was answered from an identical query of the same pixel (kCountReusedAny). The bounds that keep the fields
+    // apart (max_bounces, virtual_bounces <= SR_MAX_BOUNCES) are checked by the host before the launch.
+    uint32_t n_q;
     TravStats st;
-    uint32_t n_reused = 0;   // closest-hit queries of the reference answered from the primary-hit hand-off instead of a traversal
 };
+constexpr uint32_t kCountAny = 1u, kCountClosest = 1u << 16, kCountReusedAny = 1u << 31;
+SRD uint32_t counted_any(uint32_t n_q) { return n_q & 0xFFFFu; }
+SRD uint32_t counted_closest(uint32_t n_q) { return (n_q >> 16) & 0x7FFFu; }
 
 // TraceRay of the passes: V bit 0 = traversal statistics, V bit 2 = the two-level form of the structure
 template <int V, bool ANY>
@@ -132,7 +138,7 @@ template <int V>
 SRD Payload trace_closest_shaded(PixelCtx& cx, f3 o, f3 d, float tmin, float tmax) {
     TravHit h;
     trace_ray<V, false>(cx, true, o, d, tmin, tmax, h);
-    cx.n_closest++;
+    cx.n_q += kCountClosest;
     return shade_hit<(V & 2) != 0, (V & 4) != 0>(cx.a.sc, h);
 }
 // The shadow-ray idiom of every visibility query: prd.dist preset to 1.0, the miss shader writes -1;
@@ -141,7 +147,7 @@ template <int V>
 SRD float trace_shadow(PixelCtx& cx, f3 o, f3 d, float dist) {
     if (dist > 0.002f) {
         TravHit h;
-        cx.n_any++;
+        cx.n_q += kCountAny;
         return trace_ray<V, true>(cx, true, o, d, 0.001f, dist - 0.001f, h) ? 1.0f : -1.0f;
     }
     return -1.0f;
@@ -365,14 +371,14 @@ __global__ void tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* _
 // TraceRay it stands for). Returns found / occluded for the lane's own ray.
 template <int V, bool ANY>
 SRD bool ws_query(PixelCtx& cx, bool want, f3 o, f3 d, float tmin, float tmax, TravHit& h) {
-    if (want) { if (ANY) cx.n_any++; else cx.n_closest++; }
+    if (want) cx.n_q += ANY ? kCountAny : kCountClosest;
     return trace_ray<V, ANY>(cx, want, o, d, tmin, tmax, h);
 }
 
 template <int V>
 __global__ __launch_bounds__(kPassBlock, kPassWaves) void ris_kernel(const PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kPassBlock], sized at launch
-    PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
+    PixelCtx cx{a, s_stack + threadIdx.x, 0u, {0u, 0u}};
     const DevScene& sc = a.sc;
     uint32_t px = 0, py = 0, cost_slot = 0;
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
@@ -609,9 +615,9 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void ris_kernel(const PassA
     if (!(a.cfg.flags & SR_TRACE_FLAG_UNCOUNTED)) {
         const bool counted = (a.cfg.count_rows == 0u || (py - a.cfg.count_y0) < a.cfg.count_rows) &&      // per lane: its pixel's row
                              (a.cfg.count_cols == 0u || (px - a.cfg.count_x0) < a.cfg.count_cols);       // and column
-        flush_counter(sc.counters + 0, counted ? cx.n_closest : 0u);
-        flush_counter(sc.counters + 1, counted ? cx.n_any : 0u);
-        if (V & 1) { flush_counter(sc.counters + 2, counted ? cx.st.boxes : 0u); flush_counter(sc.counters + 3, counted ? cx.st.tris : 0u); }
+        flush_counter(sc.counters, 0, counted ? counted_closest(cx.n_q) : 0u);
+        flush_counter(sc.counters, 1, counted ? counted_any(cx.n_q) : 0u);
+        if (V & 1) { flush_counter(sc.counters, 2, counted ? cx.st.boxes : 0u); flush_counter(sc.counters, 3, counted ? cx.st.tris : 0u); }
     }
 }
 template <int V>
@@ -620,7 +626,7 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
     // (the control flow around it is predicated, not branched), so lanes without a ray of their own can take over
     // subtrees of the lanes that have one. Same operations in the same order per pixel as the branched form.
     extern __shared__ __attribute__((aligned(16))) int s_stack[];
-    PixelCtx cx{a, s_stack + threadIdx.x, 0u, 0u, {0u, 0u}};
+    PixelCtx cx{a, s_stack + threadIdx.x, 0u, {0u, 0u}};
     const DevScene& sc = a.sc;
     uint32_t px = 0, py = 0, cost_slot = 0;
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
@@ -658,7 +664,7 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
         f3 hit_normal = splat(0.0f), hit_albedo = splat(0.0f), hitPos = splat(0.0f), V_view = splat(0.0f);
         float roughness = 0.5f, metallic = 0.0f;
         if (in_loop) {
-            if (reuse_primary) { prd = load_payload(a.primary_payload + pix); cx.n_reused++; }
+            if (reuse_primary) prd = load_payload(a.primary_payload + pix);
             else prd = shade_hit<(V & 2) != 0, (V & 4) != 0>(sc, h);
             if (prd.dist < 0.0f) in_loop = false;                                      // :82-84
             else {
@@ -765,6 +771,9 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
             // ReSTIR GI spatial reuse (:224-291)
             SrReservoirGI combined; zero_reservoir_gi(combined);
             float gi_current_depth = 0.0f;
+            // true once the combined reservoir's sample is a neighbour's: its visibility ray from this very hit point was traced (or skipped
+            // as too short) a moment ago and found unoccluded — else the neighbour would not have been merged (:287)
+            bool gi_sample_seen = false;
             if (do_restir) {
                 combined = load48(reservoir_gi_cur + pix);
                 gi_current_depth = len3(hitPos - origin);
@@ -825,7 +834,7 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
                         nr.M = fminf(nr.M, 10.0f);
                         const float p_hat_neighbor = gi_target_pdf(hitPos, hit_normal, hit_albedo, metallic, ld3(nr.sample_pos), ld3(nr.sample_radiance));
                         const float gr = rnd(rng);
-                        merge_reservoirs_gi(combined, nr, p_hat_neighbor, jacobian, gr);
+                        if (merge_reservoirs_gi(combined, nr, p_hat_neighbor, jacobian, gr)) gi_sample_seen = true;
                     }
                 }
             }
@@ -841,7 +850,13 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
                     gi_x2_dist = fmaxf(len3(gi_x2_dir), 0.0001f);
                     gi_x2_dir = gi_x2_dir / gi_x2_dist;
                     gi_NdotL = fmaxf(dot3(hit_normal, gi_x2_dir), 0.0f);
-                    if (gi_NdotL > 0.0f) { gif_pending = true; want_gif = gi_x2_dist > 0.002f; }
+                    if (gi_NdotL > 0.0f) {
+                        gif_pending = true; want_gif = gi_x2_dist > 0.002f;
+                        // :304-316 would trace hitPos -> combined.sample_pos once more: same origin, and direction and length come from the
+                        // same three operations on the same operands as :262-274 — the same query, hence the same answer: not occluded.
+                        // (Answered without a traversal unless the caller asks for every query, SR_TRACE_FLAG_TRACE_EVERY_QUERY.)
+                        if (gi_sample_seen && !(a.cfg.flags & SR_TRACE_FLAG_TRACE_EVERY_QUERY)) { if (want_gif) cx.n_q |= kCountReusedAny; want_gif = false; }
+                    }
                 }
             }
             occ = ws_query<V, true>(cx, want_gif, hitPos, gi_x2_dir, 0.001f, gi_x2_dist - 0.001f, h);   // :309-316
@@ -954,10 +969,12 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
     if (!(a.cfg.flags & SR_TRACE_FLAG_UNCOUNTED)) {
         const bool counted = (a.cfg.count_rows == 0u || (py - a.cfg.count_y0) < a.cfg.count_rows) &&      // per lane: its pixel's row
                              (a.cfg.count_cols == 0u || (px - a.cfg.count_x0) < a.cfg.count_cols);       // and column
-        flush_counter(sc.counters + 0, counted ? cx.n_closest : 0u);
-        flush_counter(sc.counters + 1, counted ? cx.n_any : 0u);
-        flush_counter(sc.counters + 4, counted ? cx.n_reused : 0u);
-        if (V & 1) { flush_counter(sc.counters + 2, counted ? cx.st.boxes : 0u); flush_counter(sc.counters + 3, counted ? cx.st.tris : 0u); }
+        flush_counter(sc.counters, 0, counted ? counted_closest(cx.n_q) : 0u);
+        flush_counter(sc.counters, 1, counted ? counted_any(cx.n_q) : 0u);
+        // every pixel of the launch reaches bounce 0, and with the hand-off buffer bound that query is the one read back
+        flush_counter(sc.counters, 4, (counted && active && BOUNCES > 0 && a.primary_payload != nullptr) ? 1u : 0u);
+        flush_counter(sc.counters, 5, counted ? cx.n_q >> 31 : 0u);
+        if (V & 1) { flush_counter(sc.counters, 2, counted ? cx.st.boxes : 0u); flush_counter(sc.counters, 3, counted ? cx.st.tris : 0u); }
     }
 }
 
@@ -969,22 +986,20 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const Pas
 using namespace srd;
 
 int srk_launch_trace(const DevScene& sc, const SrRay* rays, uint32_t n, SrHit* hits, uint32_t* occluded,
-                     uint32_t* queue_head, int any, int stats, int two_level, int n_blocks, int stack_entries, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(queue_head, 0, 16, stream);
-    if (e != hipSuccess) return (int)e;
+                     int any, int stats, int two_level, int stack_entries, hipStream_t stream) {
     if (n == 0) return 0;
-    dim3 grid(n_blocks), block(kBlock);
+    dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
     const size_t lds = (size_t)(stack_entries + lds_extra_rows(two_level)) * kBlock * sizeof(int);
     const int v = (any ? 1 : 0) | (stats ? 2 : 0) | (two_level ? 4 : 0);
     switch (v) {
-        case 0: trace_queue_kernel<false, false, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
-        case 1: trace_queue_kernel<true, false, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
-        case 2: trace_queue_kernel<false, true, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
-        case 3: trace_queue_kernel<true, true, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
-        case 4: trace_queue_kernel<false, false, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
-        case 5: trace_queue_kernel<true, false, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
-        case 6: trace_queue_kernel<false, true, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
-        default: trace_queue_kernel<true, true, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded, queue_head); break;
+        case 0: trace_rays_kernel<false, false, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded); break;
+        case 1: trace_rays_kernel<true, false, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded); break;
+        case 2: trace_rays_kernel<false, true, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded); break;
+        case 3: trace_rays_kernel<true, true, false><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded); break;
+        case 4: trace_rays_kernel<false, false, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded); break;
+        case 5: trace_rays_kernel<true, false, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded); break;
+        case 6: trace_rays_kernel<false, true, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded); break;
+        default: trace_rays_kernel<true, true, true><<<grid, block, lds, stream>>>(sc, rays, n, hits, occluded); break;
     }
     return (int)hipGetLastError();
 }

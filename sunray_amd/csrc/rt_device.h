@@ -336,15 +336,18 @@ SRD void merge_reservoirs(SrReservoir& r, const SrReservoir& nr, float p_hat_new
         r.light_normal[0] = nr.light_normal[0]; r.light_normal[1] = nr.light_normal[1]; r.light_normal[2] = nr.light_normal[2];
     }
 }
-SRD void merge_reservoirs_gi(SrReservoirGI& r, const SrReservoirGI& nr, float p_hat_new, float jacobian, float random_val) {
+// (returns whether the new sample was taken: the final pass wants to know whose sample its combined reservoir ends up with)
+SRD bool merge_reservoirs_gi(SrReservoirGI& r, const SrReservoirGI& nr, float p_hat_new, float jacobian, float random_val) {
     r.M += nr.M;
     float weight = p_hat_new * nr.W * nr.M * jacobian;
     r.w_sum += weight;
-    if (random_val < (weight / fmaxf(r.w_sum, 0.0001f))) {
+    const bool taken = random_val < (weight / fmaxf(r.w_sum, 0.0001f));
+    if (taken) {
         r.sample_pos[0] = nr.sample_pos[0]; r.sample_pos[1] = nr.sample_pos[1]; r.sample_pos[2] = nr.sample_pos[2];
         r.sample_radiance[0] = nr.sample_radiance[0]; r.sample_radiance[1] = nr.sample_radiance[1]; r.sample_radiance[2] = nr.sample_radiance[2];
         r.sample_normal_packed = nr.sample_normal_packed;
     }
+    return taken;
 }
 // rt_utils.slang:278-281
 SRD f3 transform_point(const float* m, f3 p) {

@@ -52,6 +52,12 @@ def ref_closest(c):
     return c.closest_queries + c.reused_primary_hits
 
 
+def ref_any(c):
+    """Existence queries the REFERENCE issues: the traversals executed plus the final GI visibility queries whose answer was known
+    from the identical query of a spatial neighbour (SrRayCounters.reused_visibility_queries)."""
+    return c.any_queries + c.reused_visibility_queries
+
+
 def run_both(rt, oracle, desc, W, H, frames, blue_noise, cfg=None, check_counters=True, primary=None):
     """Renders `frames` consecutive frames on GPU and oracle; asserts bitwise parity every frame. `primary`: with / without
     the primary-hit hand-off buffer (None: the harness default, i.e. with)."""
@@ -83,7 +89,9 @@ def run_both(rt, oracle, desc, W, H, frames, blue_noise, cfg=None, check_counter
         assert_bits_equal(of.raw_color, h["raw_color"], "raw_color f%d" % f)
         if check_counters:
             oc, gc = osc.counters(), gsc.counters()
-            assert (oc.closest_queries, oc.any_queries) == (ref_closest(gc), gc.any_queries)
+            assert (oc.closest_queries, oc.any_queries) == (ref_closest(gc), ref_any(gc))
+            if cfg.flags & abi.TRACE_FLAG_TRACE_EVERY_QUERY:
+                assert gc.reused_visibility_queries == 0
             # with the hand-off every pixel's camera ray is traversed once per frame (by the RIS pass), without it twice
             assert gc.reused_primary_hits == (W * H if (cfg.enable_restir and cfg.virtual_bounces and gf.primary is not None) else 0)
     return osc, gsc, of, gf
@@ -360,9 +368,12 @@ def test_passes_equal_oracle(rt, oracle, blue_noise, scene_fn, W, H, frames):
 def test_passes_without_the_primary_hit_hand_off(rt, oracle, blue_noise, scene_fn, W, H, frames):
     """SrRtParams.primary_payload == NULL: the final pass traces its camera ray itself, as the reference does
     (ray_gen_final.slang:80). Same bits as with the hand-off; the ray counters then hold every query of the reference."""
-    osc, gsc, of, gf = run_both(rt, oracle, scene_fn(), W, H, frames, blue_noise, primary=False)
-    c = gsc.counters()
+    cfg = abi.SrTraceConfig.reference()
+    cfg.flags = abi.TRACE_FLAG_TRACE_EVERY_QUERY          # ... and every visibility query, also the repeated ones
+    osc, gsc, of, gf = run_both(rt, oracle, scene_fn(), W, H, frames, blue_noise, cfg=cfg, primary=False)
+    c, oc = gsc.counters(), osc.counters()
     assert c.reused_primary_hits == 0 and c.closest_queries >= 2 * W * H
+    assert (c.closest_queries, c.any_queries, c.reused_visibility_queries) == (oc.closest_queries, oc.any_queries, 0)
 
 
 def test_primary_hit_hand_off_holds_the_camera_ray_payload(rt, oracle, blue_noise):
@@ -374,6 +385,21 @@ def test_primary_hit_hand_off_holds_the_camera_ray_payload(rt, oracle, blue_nois
             osc, gsc, of, gf = run_both(rt, oracle, desc, W, H, frames, blue_noise)
             got = gf.primary.cpu().numpy().view(np.uint32).reshape(-1).view(abi.RAY_PAYLOAD)
             assert_bits_equal(of.primary, got, "primary payload")
+
+
+def test_repeated_gi_visibility_query_is_answered_once(rt, oracle, blue_noise):
+    """ray_gen_final.slang:304-316 traces hitPos -> combined.sample_pos again although :276-286 traced exactly that segment when
+    the sample came from a neighbour. The final pass answers the repeat without a traversal (it is counted apart); with
+    SR_TRACE_FLAG_TRACE_EVERY_QUERY it traverses. Both equal the oracle, which always traverses — so the two are the same query."""
+    desc = small_atrium()
+    osc, gsc, of, gf = run_both(rt, oracle, desc, 120, 72, 3, blue_noise)
+    c = gsc.counters()
+    assert c.reused_visibility_queries > 0 and ref_any(c) == osc.counters().any_queries
+    every = abi.SrTraceConfig.reference(); every.flags = abi.TRACE_FLAG_TRACE_EVERY_QUERY
+    osc2, gsc2, of2, gf2 = run_both(rt, oracle, desc, 120, 72, 3, blue_noise, cfg=every)
+    c2 = gsc2.counters()
+    assert c2.reused_visibility_queries == 0 and c2.any_queries == c.any_queries + c.reused_visibility_queries
+    assert_bits_equal(gf.host()["raw_color"], gf2.host()["raw_color"], "raw_color with / without the repeated query")
 
 
 @pytest.mark.parametrize("W,H", [(5, 3), (8, 8), (130, 17), (1000, 9), (24, 300), (129, 129)])
@@ -524,6 +550,17 @@ def test_error_behaviour(rt, blue_noise):
     with pytest.raises(SunrayError) as e:
         check(lib().sr_trace_closest(g._h, C.c_void_p(rays.data_ptr()), C.c_uint32(0x90000000), C.c_void_p(rays.data_ptr()), None))
     assert "2^31 rays" in e.value.description
+    # the passes count a pixel's queries in packed fields: bounce limits above SR_MAX_BOUNCES are refused, not wrapped
+    frame = rt.DeviceFrame(16, 16, scenes.white_noise_rgba8())
+    m = rt.camera_matrices((0, 0, 3), (0, 0, 0), 60.0, 16, 16)
+    cfg = abi.SrTraceConfig.reference(); cfg.max_bounces = abi.MAX_BOUNCES + 1
+    with pytest.raises(SunrayError) as e:
+        g.trace_final(frame, m, 0, cfg)
+    assert e.value.code == -1 and "SR_MAX_BOUNCES" in e.value.description
+    cfg = abi.SrTraceConfig.reference(); cfg.virtual_bounces = abi.MAX_BOUNCES + 1
+    with pytest.raises(SunrayError) as e:
+        g.trace_ris(frame, m, 0, cfg)
+    assert "SR_MAX_BOUNCES" in e.value.description
 
 
 # ---- post-RT compute chain --------------------------------------------------------
@@ -1123,7 +1160,7 @@ def test_4k_frame_1m_triangles(rt, oracle, blue_noise):
             sd.render_strip(gsc, gf2, m, 0, cfg, part, rank)
         assert_bits_equal(full, gf2.host()["raw_color"], "%d %s strips (+halo) compose to the 4K frame" % (world, axis))
         c = gsc.counters()      # halo pixels are traced but not counted: the strips' rays add up to the single launch's
-        assert (c.closest_queries, c.any_queries, c.reused_primary_hits) == (single.closest_queries, single.any_queries, single.reused_primary_hits)
+        assert (c.closest_queries, c.any_queries, c.reused_primary_hits, c.reused_visibility_queries) == (single.closest_queries, single.any_queries, single.reused_primary_hits, single.reused_visibility_queries)
         del gf2
 
 
@@ -1157,7 +1194,7 @@ def test_column_tiles_compose_and_count(rt, oracle, blue_noise):
     gsc.trace_ris(gf2, m, 0, cfg, tile=(0, 60, 20, 150)); osc.trace_ris(of, om, 0, cfg, tile=(0, 60, 20, 150))
     gsc.trace_final(gf2, m, 0, cfg, tile=(0, 60, 20, 150)); osc.trace_final(of, om, 0, cfg, tile=(0, 60, 20, 150))
     gc, oc = gsc.counters(), osc.counters()
-    assert (ref_closest(gc), gc.any_queries) == (oc.closest_queries, oc.any_queries) and 0 < gc.closest_queries < single_frame_closest(osc, of, om)
+    assert (ref_closest(gc), ref_any(gc)) == (oc.closest_queries, oc.any_queries) and 0 < gc.closest_queries < single_frame_closest(osc, of, om)
     assert gc.reused_primary_hits == 70 * 30
     with pytest.raises(Exception):
         gsc.trace_ris(gf2, m, 0, tile=(0, 0, W, 8))

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_struct_sizes_match_header():
     assert C.sizeof(abi.SrRtParams) == 184 and C.sizeof(abi.SrTraceConfig) == 40 and C.sizeof(abi.SrMatrices) == 256
-    assert C.sizeof(abi.SrRayCounters) == 40 and C.sizeof(abi.SrStripRects) == 56 and C.sizeof(abi.SrStripTransfer) == 16
+    assert C.sizeof(abi.SrRayCounters) == 48 and C.sizeof(abi.SrStripRects) == 56 and C.sizeof(abi.SrStripTransfer) == 16
     assert abi.SrRtParams.primary_payload.offset == 104 and abi.SrRtParams.frame_count.offset == 112
     cfg = abi.SrTraceConfig()
     _lib.lib().sr_trace_config_default(C.byref(cfg))
