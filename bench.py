@@ -475,6 +475,7 @@ def main():
                 # again where it repeats a neighbour's (SrRayCounters.reused_*). `value` counts traversals executed only.
                 "traced_queries_per_frame": total_rays / args.steps,
                 "reference_queries_per_frame": (total_rays + total_reused) / args.steps,
+                "reference_queries_mray_s": (total_rays + total_reused) / elapsed / 1e6,     # TraceRay calls of the reference answered per second
                 "primary_hit_hand_off": bool(reuse),
                 "parallelism": ("%s split into %d cost-balanced strips %s, RIS pass over strip + %d-pixel halo (recomputed, uncounted), radiance "
                                 "strips all-gathered over RCCL asynchronously (frame f's gather overlaps frame f+1); static camera, so no "
