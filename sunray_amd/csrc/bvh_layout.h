@@ -15,5 +15,8 @@ constexpr int kNodeDwords = 16;
 constexpr int kNodeBytes = kNodeDwords * 4;
 // Triangles per leaf (the leaf reference holds the count in 3 bits: <= 7). Measured on the bench frame with the host SAH
 // tree: 1 -> 3.11, 2 -> 3.65, 3 -> 3.64, 4 -> 3.50, 6 -> 3.36 Gray/s (fewer triangle tests per ray beat fewer nodes).
-constexpr unsigned kLeafMax = 2;
+#ifndef SR_LEAF_MAX
+#define SR_LEAF_MAX 2
+#endif
+constexpr unsigned kLeafMax = SR_LEAF_MAX;
 }  // namespace srl

@@ -427,42 +427,50 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                 if (node < 0 && node != kSentinel && leaf == 0 && (!TL || in_blas)) { leaf = node; leaf_inst = inst; node = pop(); }
             }
         }
+        // ---- triangle phase: two triangles of the lane's leaf per round trip (the builders make leaves of <= 2; an iteration is
+        // one dependent gather, ~1500 cycles, against ~60 VALU instructions per test) ----
         while (leaf != 0) {
             const uint32_t lv = ~(uint32_t)leaf;
             const uint32_t slot = lv >> 3, cnt = lv & 7u;
-            leaf = cnt > 1u ? (int)~(((slot + 1u) << 3) | (cnt - 1u)) : 0;
-            const uint32_t cur_inst = leaf_inst;          // instance of THIS triangle (the chaining below may move on to another leaf)
+            const bool two = cnt >= 2u;
+            leaf = cnt > 2u ? (int)~(((slot + 2u) << 3) | (cnt - 2u)) : 0;
+            const uint32_t cur_inst = leaf_inst;          // instance of THESE triangles (the chaining below may move on to another leaf)
             if (leaf == 0 && node < 0 && (!TL || in_blas)) { leaf = node; leaf_inst = inst; node = pop(); }
             if (cnt == 0u) continue;
-            const float4 t0 = tris[(size_t)slot * 3 + 0];
-            const float4 t1 = tris[(size_t)slot * 3 + 1];
-            const float4 t2 = tris[(size_t)slot * 3 + 2];
-            float t, u, v;
-            if (STATS) st.tris += 1;
-            bool is_hit;
-            uint32_t gid;
+            const uint32_t slot_b = two ? slot + 1u : slot;   // a lone triangle is read twice (same lines), its second result unused
+            const float4 t0 = tris[(size_t)slot * 3 + 0], t1 = tris[(size_t)slot * 3 + 1], t2 = tris[(size_t)slot * 3 + 2];
+            const float4 s0 = tris[(size_t)slot_b * 3 + 0], s1 = tris[(size_t)slot_b * 3 + 1], s2 = tris[(size_t)slot_b * 3 + 2];
+            float ta, ua, va, tb, ub, vb;
+            if (STATS) st.tris += two ? 2u : 1u;
+            bool hit_a, hit_b;
+            uint32_t gid_a, gid_b;
             if (TL) {
                 // object-space v0, v1, v2 -> world space with transform_point (rt_utils.slang:278-281), exactly as the one-level form
                 // flattens a triangle; the test itself runs on the world-space ray
                 const float4* q = reinterpret_cast<const float4*>(sc.tl_instances + cur_inst);
                 const float4 m0 = q[3], m1 = q[4], m2 = q[5];
                 const bool baked = (__float_as_uint(q[7].z) & 1u) != 0u;                     // its records already hold world-space vertices
-                const f3 a = mk3(t0.x, t0.y, t0.z), b = mk3(t0.w, t1.x, t1.y), c = mk3(t1.z, t1.w, t2.x);
-                f3 wa = mk3(((m0.x * a.x + m0.y * a.y) + m0.z * a.z) + m0.w * 1.0f, ((m1.x * a.x + m1.y * a.y) + m1.z * a.z) + m1.w * 1.0f,
-                                  ((m2.x * a.x + m2.y * a.y) + m2.z * a.z) + m2.w * 1.0f);
-                f3 wb = mk3(((m0.x * b.x + m0.y * b.y) + m0.z * b.z) + m0.w * 1.0f, ((m1.x * b.x + m1.y * b.y) + m1.z * b.z) + m1.w * 1.0f,
-                            ((m2.x * b.x + m2.y * b.y) + m2.z * b.z) + m2.w * 1.0f);
-                f3 wc = mk3(((m0.x * c.x + m0.y * c.y) + m0.z * c.z) + m0.w * 1.0f, ((m1.x * c.x + m1.y * c.y) + m1.z * c.z) + m1.w * 1.0f,
-                            ((m2.x * c.x + m2.y * c.y) + m2.z * c.z) + m2.w * 1.0f);
-                if (baked) { wa = a; wb = b; wc = c; }
-                is_hit = intersect_tri(o, d, wa, wb - wa, wc - wa, tmin, tmax, t, u, v);
-                gid = sc.tl_instances[cur_inst].tri_offset + __float_as_uint(t2.y);
+                auto to_world = [&](f3 p) {
+                    return baked ? p : mk3(((m0.x * p.x + m0.y * p.y) + m0.z * p.z) + m0.w * 1.0f, ((m1.x * p.x + m1.y * p.y) + m1.z * p.z) + m1.w * 1.0f,
+                                           ((m2.x * p.x + m2.y * p.y) + m2.z * p.z) + m2.w * 1.0f);
+                };
+                const f3 wa = to_world(mk3(t0.x, t0.y, t0.z)), wb = to_world(mk3(t0.w, t1.x, t1.y)), wc = to_world(mk3(t1.z, t1.w, t2.x));
+                hit_a = intersect_tri(o, d, wa, wb - wa, wc - wa, tmin, tmax, ta, ua, va);
+                const f3 xa = to_world(mk3(s0.x, s0.y, s0.z)), xb = to_world(mk3(s0.w, s1.x, s1.y)), xc = to_world(mk3(s1.z, s1.w, s2.x));
+                hit_b = intersect_tri(o, d, xa, xb - xa, xc - xa, tmin, tmax, tb, ub, vb) && two;
+                const uint32_t off = sc.tl_instances[cur_inst].tri_offset;
+                gid_a = off + __float_as_uint(t2.y); gid_b = off + __float_as_uint(s2.y);
             } else {
-                is_hit = intersect_tri(o, d, mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), tmin, tmax, t, u, v);
-                gid = __float_as_uint(t2.y);
+                hit_a = intersect_tri(o, d, mk3(t0.x, t0.y, t0.z), mk3(t0.w, t1.x, t1.y), mk3(t1.z, t1.w, t2.x), tmin, tmax, ta, ua, va);
+                hit_b = intersect_tri(o, d, mk3(s0.x, s0.y, s0.z), mk3(s0.w, s1.x, s1.y), mk3(s1.z, s1.w, s2.x), tmin, tmax, tb, ub, vb) && two;
+                gid_a = __float_as_uint(t2.y); gid_b = __float_as_uint(s2.y);
             }
-            if (is_hit) {
+            if (hit_a || hit_b) {
                 if (ANY) { keys[root] = 0ull; node = kSentinel; sp = sb; leaf = 0; if (TL) { in_blas = false; } break; }
+                // the better of the two by the tie rule (smallest t, then lowest id), then one update as before
+                const bool take_b = hit_b && (!hit_a || tb < ta || (tb == ta && gid_b < gid_a));
+                const float t = take_b ? tb : ta, u = take_b ? ub : ua, v = take_b ? vb : va;
+                const uint32_t gid = take_b ? gid_b : gid_a, hit_slot = take_b ? slot_b : slot;
                 if (t < best_t || (t == best_t && gid < best_gid)) {
                     best_t = t; best_gid = gid;
                     cull = fminf(cull, fmaf(fabsf(t), 1e-5f, t));
@@ -470,7 +478,7 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
                     atomicMin(&keys[root], key);
                     if (keys[root] == key) {   // this lane holds the minimum: its payload stands
                         pay[0 * stride + root] = __float_as_int(t); pay[1 * stride + root] = __float_as_int(u);
-                        pay[2 * stride + root] = __float_as_int(v); pay[3 * stride + root] = (int)slot;
+                        pay[2 * stride + root] = __float_as_int(v); pay[3 * stride + root] = (int)hit_slot;
                         if (TL) pay[4 * stride + root] = (int)cur_inst;
                     }
                 }
