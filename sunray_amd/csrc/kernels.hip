@@ -24,6 +24,11 @@ static int lds_extra_rows(int two_level) { return two_level ? kWsRowsTl : kWsRow
 #define SR_PASS_WAVES 4
 #endif
 constexpr int kPassWaves = SR_PASS_WAVES;      // __launch_bounds__ second argument on HIP: waves per SIMD (4 -> VGPR budget 128)
+// The two-level variants (V bit 2) carry ~30 more live registers (instance, object-space ray, padding): at the 128-register budget
+// of 4 waves per SIMD final_kernel<6> spills 35-43 of them, and with that much scratch traffic in the stealing loop its results
+// depended on unrelated code changes (a no-op edit of the node loop broke test_two_level_passes_equal_oracle[small_atrium]; the
+// same source at 3 waves per SIMD, 160 registers, no spills, passes). They run at 3 waves per SIMD.
+constexpr int pass_waves(int v) { return (v & 4) ? (kPassWaves < 3 ? kPassWaves : 3) : kPassWaves; }
 
 // Wave-wide sum, then one atomic per wave (rays are counted, not estimated: SURVEY.md §8d).
 SRD void flush_counter(unsigned long long* counters, int which, uint32_t v) {
@@ -376,7 +381,7 @@ SRD bool ws_query(PixelCtx& cx, bool want, f3 o, f3 d, float tmin, float tmax, T
 }
 
 template <int V>
-__global__ __launch_bounds__(kPassBlock, kPassWaves) void ris_kernel(const PassArgs a) {
+__global__ __launch_bounds__(kPassBlock, pass_waves(V)) void ris_kernel(const PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) int s_stack[];   // [stack_entries][kPassBlock], sized at launch
     PixelCtx cx{a, s_stack + threadIdx.x, 0u, {0u, 0u}};
     const DevScene& sc = a.sc;
@@ -621,7 +626,7 @@ __global__ __launch_bounds__(kPassBlock, kPassWaves) void ris_kernel(const PassA
     }
 }
 template <int V>
-__global__ __launch_bounds__(kPassBlock, kPassWaves) void final_kernel(const PassArgs a) {
+__global__ __launch_bounds__(kPassBlock, pass_waves(V)) void final_kernel(const PassArgs a) {
     // Flattened form of the pass for the work-stealing traversal: every trace point is reached by ALL lanes of the wave
     // (the control flow around it is predicated, not branched), so lanes without a ray of their own can take over
     // subtrees of the lanes that have one. Same operations in the same order per pixel as the branched form.

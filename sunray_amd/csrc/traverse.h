@@ -217,6 +217,7 @@ SRD int pick(int4 c, uint32_t i) {   // two levels of selects (v_cndmask), no br
 // world-space ray, or — once the donor has none left — one of the instance with its object-space ray.
 // ---------------------------------------------------------------------------------------------
 constexpr int kWsRows = 7, kWsRowsTl = 8;
+constexpr int kEarlyTriWalking = 16, kEarlyTriBlocked = 16;   // round 3 sweep: 8 / 12 / 16 / 24 / 32 walking x 8 / 16 / 20 / 24 / 32 blocked
 SRD uint32_t ord_f32(float f) { const uint32_t b = __float_as_uint(f + 0.0f); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
 SRD float unord_f32(uint32_t k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
 SRD uint32_t lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
@@ -280,11 +281,20 @@ SRD bool traverse_ws(const DevScene& sc, bool want, f3 o, f3 d, float tmin, floa
         for (;;) {
             // `inner`: the lane has a node-phase step to do — an inner node, or (two-level) a top-level leaf to enter
             const bool inner = node != kSentinel && (node >= 0 || (TL && !in_blas));
-            if (__builtin_amdgcn_ballot_w64(inner && leaf == 0) == 0ull) break;   // every walking lane holds a (postponed) leaf: on to the triangles
+            // On to the triangles when every walking lane holds a (postponed) leaf — or already when most of the wave is BLOCKED (holds a
+            // postponed leaf and has arrived at a second one) and only a few lanes still walk: the blocked lanes would wait for them.
+            // Progress: an early exit needs a blocked lane, and the triangle phase consumes its leaf.
+            {
+                const unsigned long long walking = __builtin_amdgcn_ballot_w64(inner && leaf == 0);
+                if (walking == 0ull) break;
+                if ((int)__popcll(walking) <= kEarlyTriWalking &&
+                    (int)__popcll(__builtin_amdgcn_ballot_w64(node != kSentinel && node < 0 && leaf != 0 && (!TL || in_blas))) >= kEarlyTriBlocked) break;
+            }
             const bool idle = node == kSentinel && leaf == 0;
             const unsigned long long idle_mask = __builtin_amdgcn_ballot_w64(idle);
             if (idle_mask != 0ull) {
-                const bool can_give = inner && sp > sb;
+                // donors: every lane with a node or leaf in hand and a spare stack entry — blocked lanes too (they wait, their subtrees need not)
+                const bool can_give = node != kSentinel && sp > sb;
                 const unsigned long long donor_mask = __builtin_amdgcn_ballot_w64(can_give);
                 if (donor_mask != 0ull) {
                     const uint32_t n = min((uint32_t)__popcll(idle_mask), (uint32_t)__popcll(donor_mask));
