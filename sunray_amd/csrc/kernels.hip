@@ -28,7 +28,10 @@ constexpr int kPassWaves = SR_PASS_WAVES;      // __launch_bounds__ second argum
 // of 4 waves per SIMD final_kernel<6> spills 35-43 of them, and with that much scratch traffic in the stealing loop its results
 // depended on unrelated code changes (a no-op edit of the node loop broke test_two_level_passes_equal_oracle[small_atrium]; the
 // same source at 3 waves per SIMD, 160 registers, no spills, passes). They run at 3 waves per SIMD.
-constexpr int pass_waves(int v) { return (v & 4) ? (kPassWaves < 3 ? kPassWaves : 3) : kPassWaves; }
+#ifndef SR_TL_PASS_WAVES
+#define SR_TL_PASS_WAVES 3
+#endif
+constexpr int pass_waves(int v) { return (v & 4) ? (kPassWaves < SR_TL_PASS_WAVES ? kPassWaves : SR_TL_PASS_WAVES) : kPassWaves; }
 
 // Wave-wide sum, then one atomic per wave (rays are counted, not estimated: SURVEY.md §8d).
 SRD void flush_counter(unsigned long long* counters, int which, uint32_t v) {
