@@ -1,8 +1,8 @@
 """What would sorting secondary rays buy? The GI bounce rays of the bench frame (cosine-distributed directions from the primary
-hit points) traced by the stand-alone persistent tracer in three orders: as the passes issue them (pixel order in 8x8 tiles),
+hit points) traced by the stand-alone tracer in three orders: as the passes issue them (pixel order in 8x8 tiles),
 sorted by direction octant + Morton code of the origin (the binning a global ray queue would do), and shuffled (the worst
 case). Each set: 1 warm + 5 timed launches, in this order — under `rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum` the dispatches of
-trace_queue_kernel<false,false> come in groups of six per set (pmc_by_group below reads the CSV back)."""
+trace_rays_kernel<false,false,false> come in groups of six per set (pmc_by_group below reads the CSV back)."""
 import sys, os, glob, csv
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,7 +12,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--pmc-csv":      # post-process: mean L
     rows = {}
     for f in glob.glob(sys.argv[2] + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "trace_queue_kernel<false, false>" in r["Kernel_Name"]:
+            if "trace_rays_kernel<false, false, false>" in r["Kernel_Name"]:
                 rows.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
     ids = sorted(rows)
     names = ["primary (fills the hit points)", "bounce, pixel order", "bounce, sorted (octant + origin Morton)", "bounce, shuffled"]
