@@ -41,7 +41,9 @@ def run(name, desc, W, H, frames, cfg, strips=0):
         osc.trace_final(of, om, f, cfg); gsc.trace_final(gf, gm, f, cfg)
         h = gf.host()
         oc, gc = osc.counters(), gsc.counters()
-        ok = same(of.raw_color, h["raw_color"]) and (oc.closest_queries, oc.any_queries) == (gc.closest_queries, gc.any_queries)
+        # the oracle traverses every TraceRay of the reference; the GPU answers the final pass's camera-ray query from the RIS pass's payload and
+        # its repeated GI visibility query from the neighbour's identical one — counted apart (SrRayCounters.reused_*)
+        ok = same(of.raw_color, h["raw_color"]) and (oc.closest_queries, oc.any_queries) == (gc.closest_queries + gc.reused_primary_hits, gc.any_queries + gc.reused_visibility_queries)
         if cfg.enable_restir:
             cur = f & 1
             ok = ok and same(of.depth, h["depth"]) and same(of.normal, h["normal"]) and same(of.diffuse, h["diffuse"]) and same(of.motion, h["motion"]) \
